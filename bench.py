@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mcells/s regridded, bilinear, 4000x3000 -> 2000x2000 f32 (BASELINE.json).
+
+One "step" = one pass of the hot path over one batch of slices: ONE launch of the bilinear apply
+kernel over NZ time x level slices that already sit in HBM (default NZ = 200, the north-star batch;
+the geometry is BASELINE.json configs[1], "C2").  N > 1: one process per GPU, every rank regrids its own
+NZ slices with a replicated plan (weak scaling, no data-path collective -- the reference's MPI mode shards
+time steps the same way, src/NetCDF_CDMWriter.cc:632-646); the RCCL gather of the finished slices to
+rank 0 ("write-back") is timed separately and reported beside the metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_plan(fa, torch, wl, method, stream):
+    """Plan build on the GPU: target lon/lat -> fractional source indices -> compact plan."""
+    lon, lat = wl.target_lonlat()
+    ax, ay = wl.source_axes_rad()
+    d_px = torch.from_numpy(lon).cuda()
+    d_py = torch.from_numpy(lat).cuda()
+    fa.points2position_device(d_px.data_ptr(), d_px.numel(), ax, fa.LONGITUDE, stream)
+    fa.points2position_device(d_py.data_ptr(), d_py.numel(), ay, fa.LATITUDE, stream)
+    plan = fa.RegridPlan.from_device(method, d_px.data_ptr(), d_py.data_ptr(), d_px.numel(),
+                                     wl.inX, wl.inY, wl.outX, wl.outY, stream)
+    torch.cuda.synchronize()
+    return plan, d_px.cpu().numpy(), d_py.cpu().numpy()
+
+
+def make_slices(torch, base, nz):
+    """slice k = base + 0.01 k, resident in HBM ([nz][inY][inX] f32)."""
+    d_base = torch.from_numpy(base).cuda()
+    d_in = torch.empty((nz,) + base.shape, dtype=torch.float32, device="cuda")
+    for k0 in range(0, nz, 16):
+        k1 = min(nz, k0 + 16)
+        off = 0.01 * torch.arange(k0, k1, dtype=torch.float32, device="cuda")
+        d_in[k0:k1] = d_base[None] + off[:, None, None]
+    return d_in
+
+
+def time_launches(torch, fn, steps, warmup, dist_on):
+    """W untimed + K timed launches; returns (wall seconds of the K steps, per-launch kernel ms list)."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()  # on torch's current stream, the stream the kernel is launched on
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, [a.elapsed_time(b) for a, b in ev]
+
+
+def cpu_baseline(wl, px, py, base, budget_s):
+    """The CPU oracle (restatement of the reference's OpenMP loop, src/CachedInterpolation.cc:125-144) timed on
+    this host: one time step of `levels` levels per call, repeated for about budget_s seconds."""
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    levels = 4
+    f = np.stack([base + np.float32(0.01 * k) for k in range(levels)])
+    cells = levels * wl.outX * wl.outY
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while True:
+        t0 = time.perf_counter()
+        oracle.interpolate_values(oracle.BILINEAR, px, py, f, wl.inX, wl.inY, wl.outX, wl.outY, nthreads=cores)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() > t_end and len(times) >= 3:
+            break
+    t1 = time.perf_counter()
+    oracle.interpolate_values(oracle.BILINEAR, px, py, f[:1], wl.inX, wl.inY, wl.outX, wl.outY, nthreads=1)
+    single = time.perf_counter() - t1
+    med = float(np.median(times))
+    return {
+        "value": cells / med / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+        "sample": "%d calls of one time step x %d levels (%.0f Mcells each) of the same 4000x3000->2000x2000 bilinear "
+                  "plan, OpenMP over output cells on %d threads, median; 1 thread: %.1f Mcells/s"
+                  % (len(times), levels, cells / 1e6, cores, wl.outX * wl.outY / single / 1e6),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nz", type=int, default=200, help="time x level slices per GPU per step")
+    ap.add_argument("--method", default="bilinear", choices=["bilinear", "bicubic", "nearest"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-slice and gather measurements")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fimex_amd import capi as fa
+    import workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    fa.load()
+    fa.set_device(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    method = {"bilinear": fa.BILINEAR, "bicubic": fa.BICUBIC, "nearest": fa.NEAREST_NEIGHBOR}[args.method]
+    stencil = {"bilinear": 2, "bicubic": 4, "nearest": 1}[args.method]
+    wl = workloads.BilinearRotatedPole()
+    t0 = time.perf_counter()
+    plan, px, py = build_plan(fa, torch, wl, method, stream)
+    t_plan = time.perf_counter() - t0
+    info = plan.info()
+    base = wl.base_field()
+    nz = args.nz
+    d_in = make_slices(torch, base, nz)
+    d_out = torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream)
+
+    wall, kernel_ms = time_launches(torch, step, args.steps, args.warmup, dist_on)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if dist_on:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall_max = float(wall_t.item())
+    cells_per_step = nz * wl.outX * wl.outY
+    ms_per_step = wall_max / args.steps * 1e3
+    value = world * cells_per_step / (wall_max / args.steps) / 1e6
+
+    # roofline of the dominant (only) kernel: algorithmic bytes per launch / average launch duration
+    n_src_bbox = wl.inX * wl.inY
+    n_src_touched = workloads.touched_source_cells(px, py, wl.inX, wl.inY, stencil) if rank == 0 else 0
+    alg_bytes = nz * 4 * (n_src_touched + wl.outX * wl.outY) + info["planBytes"]
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("%s_nz%d" % (args.method, nz))
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "Mcells/s regridded (%s, 4000x3000->2000x2000 f32)" % args.method,
+        "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1] geometry (4000x3000 0.01-deg lon/lat -> 2000x2000 rotated pole, %s), "
+                        "%d time x level slices per GPU per step resident in HBM (north-star batch)" % (args.method, nz),
+            "slices_per_gpu": nz, "sharding": "slices over GPUs, plan replicated, no data-path collective",
+            "plan_build_s": t_plan, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "kernel": "bilinear_apply" if args.method == "bilinear" else args.method + "_apply",
+            "kernel_ms_avg": avg_kernel_ms, "kernel_ms_min": float(np.min(kernel_ms)),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "n_src_touched": n_src_touched, "n_src_bbox": n_src_bbox, "plan_bytes": info["planBytes"],
+        },
+    }
+
+    if not args.no_extras:
+        # configs[1] proper: one time step, one slice (plan read not amortised over z)
+        wall1, k1 = time_launches(torch, lambda: plan.apply_device(d_in.data_ptr(), 1, d_out.data_ptr(), stream),
+                                  max(args.steps, 20), args.warmup, False)
+        b1 = 4 * (n_src_touched + wl.outX * wl.outY) + info["planBytes"]
+        result["single_slice"] = {"workload": "configs[1], nz = 1", "kernel_ms_avg": float(np.mean(k1)),
+                                  "Mcells_per_s": wl.outX * wl.outY / (float(np.mean(k1)) * 1e-3) / 1e6,
+                                  "achieved_GBps": b1 / (float(np.mean(k1)) * 1e-3) / 1e9}
+        if dist_on:
+            # write-back: RCCL gather of every rank's finished slices to rank 0 over xGMI, outside the metric
+            gl = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
+            dist.barrier()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            dist.gather(d_out, gl, dst=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter() - tg
+            result["gather"] = {"seconds": tg, "bytes_per_peer": d_out.numel() * 4,
+                                "GBps_into_root": (world - 1) * d_out.numel() * 4 / tg / 1e9,
+                                "note": "dist.gather (RCCL send/recv) of all output slices to rank 0; not part of value"}
+            del gl
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            result["cpu_baseline"] = cpu_baseline(wl, px, py, base, args.cpu_seconds)
+        except Exception as e:  # the oracle is only the reported baseline; the GPU numbers stand without it
+            result["cpu_baseline"] = {"value": None, "unit": "Mcells/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,257 @@
+"""ctypes binding of the C ABI in include/fimex_amd.h (libfimex_amd.so).
+
+Harness glue for tests/ and bench.py: numpy arrays in and out for the *_host entry points,
+raw device pointers (e.g. torch tensors' data_ptr()) for the *_device ones.  No compute
+happens here and there is no fallback: a missing library or a missing GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfimex_amd.so")
+
+OK, ERROR = 1, -1
+
+# include/fimex_amd.h (values of mifi_interpol_method)
+NEAREST_NEIGHBOR, BILINEAR, BICUBIC, COORD_NN, COORD_NN_KD = 0, 1, 2, 3, 4
+FORWARD_SUM, FORWARD_MEAN, FORWARD_MEDIAN, FORWARD_MAX, FORWARD_MIN = 5, 6, 7, 8, 9
+FORWARD_UNDEF_SUM, FORWARD_UNDEF_MEAN, FORWARD_UNDEF_MEDIAN, FORWARD_UNDEF_MAX, FORWARD_UNDEF_MIN = 10, 11, 12, 13, 14
+PROJ_AXIS, LONGITUDE, LATITUDE = 0, 1, 2
+
+
+class FimexAmdError(RuntimeError):
+    """FIMEX_AMD_ERROR from the library; the message is fimex_amd_last_error()."""
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [("funcType", ctypes.c_int), ("device", ctypes.c_int),
+                ("inX", ctypes.c_size_t), ("inY", ctypes.c_size_t), ("outX", ctypes.c_size_t), ("outY", ctypes.c_size_t),
+                ("planBytes", ctypes.c_size_t), ("undefinedCells", ctypes.c_size_t), ("borderCells", ctypes.c_size_t),
+                ("maxBucket", ctypes.c_size_t), ("mappedSourceCells", ctypes.c_size_t)]
+
+
+_F = ctypes.POINTER(ctypes.c_float)
+_D = ctypes.POINTER(ctypes.c_double)
+_Z = ctypes.c_size_t
+_ZP = ctypes.POINTER(ctypes.c_size_t)
+_V = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/fimex_amd.h declares
+SYMBOLS = {
+    "fimex_amd_last_error": (ctypes.c_char_p, []),
+    "fimex_amd_abi_version": (ctypes.c_int, []),
+    "fimex_amd_device_count": (ctypes.c_int, []),
+    "fimex_amd_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "fimex_amd_regrid_plan_create": (ctypes.c_int, [ctypes.c_int, _D, _D, _Z, _Z, _Z, _Z, _Z, ctypes.POINTER(_V)]),
+    "fimex_amd_regrid_plan_create_device": (ctypes.c_int, [ctypes.c_int, _V, _V, _Z, _Z, _Z, _Z, _Z, _V, ctypes.POINTER(_V)]),
+    "fimex_amd_regrid_plan_destroy": (ctypes.c_int, [_V]),
+    "fimex_amd_regrid_plan_info": (ctypes.c_int, [_V, ctypes.POINTER(PlanInfo)]),
+    "fimex_amd_regrid_apply_host": (ctypes.c_int, [_V, _F, _Z, _F, _Z, _ZP]),
+    "fimex_amd_regrid_apply_device": (ctypes.c_int, [_V, _V, _Z, _V, _V]),
+    "fimex_amd_vector_plan_create": (ctypes.c_int, [_D, _Z, _Z, ctypes.POINTER(_V)]),
+    "fimex_amd_vector_plan_destroy": (ctypes.c_int, [_V]),
+    "fimex_amd_vector_reproject_values_host": (ctypes.c_int, [_V, _F, _F, _Z]),
+    "fimex_amd_vector_reproject_values_device": (ctypes.c_int, [_V, _V, _V, _Z, _V]),
+    "fimex_amd_vector_reproject_direction_host": (ctypes.c_int, [_V, _F, _Z]),
+    "fimex_amd_vector_reproject_direction_device": (ctypes.c_int, [_V, _V, _Z, _V]),
+    "fimex_amd_fill2d_host": (ctypes.c_int, [_Z, _Z, _Z, _F, ctypes.c_float, ctypes.c_float, _Z, _ZP]),
+    "fimex_amd_fill2d_device": (ctypes.c_int, [_Z, _Z, _Z, _V, ctypes.c_float, ctypes.c_float, _Z, _ZP, _V]),
+    "fimex_amd_creepfill2d_host": (ctypes.c_int, [_Z, _Z, _Z, _F, ctypes.c_ushort, ctypes.c_char, _ZP]),
+    "fimex_amd_creepfill2d_device": (ctypes.c_int, [_Z, _Z, _Z, _V, ctypes.c_ushort, ctypes.c_char, _ZP, _V]),
+    "fimex_amd_creepfillval2d_host": (ctypes.c_int, [_Z, _Z, _Z, _F, ctypes.c_float, ctypes.c_ushort, ctypes.c_char, _ZP]),
+    "fimex_amd_creepfillval2d_device": (ctypes.c_int, [_Z, _Z, _Z, _V, ctypes.c_float, ctypes.c_ushort, ctypes.c_char, _ZP, _V]),
+    "fimex_amd_bad2nan_device": (ctypes.c_int, [_V, _Z, ctypes.c_float, _V]),
+    "fimex_amd_nan2bad_device": (ctypes.c_int, [_V, _Z, ctypes.c_float, _V]),
+    "fimex_amd_points2position_device": (ctypes.c_int, [_V, _Z, _D, ctypes.c_int, ctypes.c_int, _V]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfimex_amd.so; raises when it has not been built (python -m fimex_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FimexAmdError("%s is missing: build it with `python -m fimex_amd.build` (needs hipcc); "
+                            "there is no CPU fallback" % LIB_PATH)
+    try:
+        # share the HIP runtime torch has already mapped (same SONAME) when torch is in the process
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise FimexAmdError(load().fimex_amd_last_error().decode() or "fimex_amd call failed")
+
+
+def device_count():
+    return load().fimex_amd_device_count()
+
+
+def set_device(ordinal):
+    _check(load().fimex_amd_set_device(ordinal))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_F)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_D)
+
+
+class RegridPlan:
+    """fimex_amd_regrid_plan: backward (per output cell) or forward (per input cell) positions."""
+
+    def __init__(self, funcType, pointsOnXAxis, pointsOnYAxis, inX, inY, outX, outY):
+        px, py = _f64(pointsOnXAxis).ravel(), _f64(pointsOnYAxis).ravel()
+        if px.size != py.size:
+            raise ValueError("position arrays differ in size")
+        self._h = _V()
+        self.inX, self.inY, self.outX, self.outY = inX, inY, outX, outY
+        _check(load().fimex_amd_regrid_plan_create(funcType, _dp(px), _dp(py), px.size, inX, inY, outX, outY,
+                                                   ctypes.byref(self._h)))
+
+    @classmethod
+    def from_device(cls, funcType, d_px, d_py, nPoints, inX, inY, outX, outY, stream=0):
+        self = cls.__new__(cls)
+        self._h = _V()
+        self.inX, self.inY, self.outX, self.outY = inX, inY, outX, outY
+        _check(load().fimex_amd_regrid_plan_create_device(funcType, d_px, d_py, nPoints, inX, inY, outX, outY,
+                                                          stream, ctypes.byref(self._h)))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().fimex_amd_regrid_plan_destroy(self._h)
+            self._h = _V()
+
+    __del__ = close
+
+    def info(self):
+        i = PlanInfo()
+        _check(load().fimex_amd_regrid_plan_info(self._h, ctypes.byref(i)))
+        return {k: getattr(i, k) for k, _ in PlanInfo._fields_}
+
+    def apply_host(self, inData):
+        """interpolateValues: [nz][inY][inX] float32 host array -> [nz][outY][outX]."""
+        a = _f32(inData).ravel()
+        n = _Z(0)
+        _check(load().fimex_amd_regrid_apply_host(self._h, _fp(a), a.size, None, 0, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        _check(load().fimex_amd_regrid_apply_host(self._h, _fp(a), a.size, _fp(out), out.size, ctypes.byref(n)))
+        return out.reshape(-1, self.outY, self.outX)
+
+    def apply_device(self, d_in, nz, d_out, stream=0):
+        _check(load().fimex_amd_regrid_apply_device(self._h, d_in, nz, d_out, stream))
+
+
+class VectorPlan:
+    """fimex_amd_vector_plan from the reference's double[4*ox*oy] rotation matrix."""
+
+    def __init__(self, matrix, ox, oy):
+        m = _f64(matrix).ravel()
+        if m.size != 4 * ox * oy:
+            raise ValueError("matrix must hold 4*ox*oy doubles")
+        self._h = _V()
+        self.ox, self.oy = ox, oy
+        _check(load().fimex_amd_vector_plan_create(_dp(m), ox, oy, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().fimex_amd_vector_plan_destroy(self._h)
+            self._h = _V()
+
+    __del__ = close
+
+    def reproject_values_host(self, u, v):
+        u, v = _f32(u).copy(), _f32(v).copy()
+        _check(load().fimex_amd_vector_reproject_values_host(self._h, _fp(u.reshape(-1)), _fp(v.reshape(-1)), u.size))
+        return u, v
+
+    def reproject_values_device(self, d_u, d_v, oz, stream=0):
+        _check(load().fimex_amd_vector_reproject_values_device(self._h, d_u, d_v, oz, stream))
+
+    def reproject_direction_host(self, angles):
+        a = _f32(angles).copy()
+        _check(load().fimex_amd_vector_reproject_direction_host(self._h, _fp(a.reshape(-1)), a.size))
+        return a
+
+    def reproject_direction_device(self, d_angles, oz, stream=0):
+        _check(load().fimex_amd_vector_reproject_direction_device(self._h, d_angles, oz, stream))
+
+
+def _slices(field):
+    a = _f32(field).copy()
+    if a.ndim == 2:
+        a = a[None]
+    nz, ny, nx = a.shape
+    return a, nx, ny, nz
+
+
+def fill2d_host(field, relaxCrit, corrEff, maxLoop):
+    a, nx, ny, nz = _slices(field)
+    n = (ctypes.c_size_t * nz)()
+    _check(load().fimex_amd_fill2d_host(nx, ny, nz, _fp(a.reshape(-1)), relaxCrit, corrEff, maxLoop, n))
+    return a.reshape(np.shape(field)), list(n)
+
+
+def creepfill2d_host(field, repeat, setWeight):
+    a, nx, ny, nz = _slices(field)
+    n = (ctypes.c_size_t * nz)()
+    _check(load().fimex_amd_creepfill2d_host(nx, ny, nz, _fp(a.reshape(-1)), repeat, bytes([setWeight & 0xFF]), n))
+    return a.reshape(np.shape(field)), list(n)
+
+
+def creepfillval2d_host(field, defaultVal, repeat, setWeight):
+    a, nx, ny, nz = _slices(field)
+    n = (ctypes.c_size_t * nz)()
+    _check(load().fimex_amd_creepfillval2d_host(nx, ny, nz, _fp(a.reshape(-1)), defaultVal, repeat,
+                                                bytes([setWeight & 0xFF]), n))
+    return a.reshape(np.shape(field)), list(n)
+
+
+def fill2d_device(d_field, nx, ny, nz, relaxCrit, corrEff, maxLoop, stream=0):
+    n = (ctypes.c_size_t * nz)()
+    _check(load().fimex_amd_fill2d_device(nx, ny, nz, d_field, relaxCrit, corrEff, maxLoop, n, stream))
+    return list(n)
+
+
+def creepfill2d_device(d_field, nx, ny, nz, repeat, setWeight, stream=0):
+    n = (ctypes.c_size_t * nz)()
+    _check(load().fimex_amd_creepfill2d_device(nx, ny, nz, d_field, repeat, bytes([setWeight & 0xFF]), n, stream))
+    return list(n)
+
+
+def bad2nan_device(d_data, n, bad, stream=0):
+    _check(load().fimex_amd_bad2nan_device(d_data, n, bad, stream))
+
+
+def nan2bad_device(d_data, n, bad, stream=0):
+    _check(load().fimex_amd_nan2bad_device(d_data, n, bad, stream))
+
+
+def points2position_device(d_points, n, axis, axis_type=PROJ_AXIS, stream=0):
+    ax = _f64(axis).ravel()
+    _check(load().fimex_amd_points2position_device(d_points, n, _dp(ax), ax.size, axis_type, stream))

@@ -1,0 +1,431 @@
+// extern "C" boundary of libfimex_amd.so (include/fimex_amd.h).
+#include "plan.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
+namespace fimex_amd {
+
+namespace {
+thread_local std::string g_lastError;
+}
+
+void set_last_error(const std::string& msg) { g_lastError = msg; }
+
+int tuning(const char* name, int fallback)
+{
+    static std::mutex mu;
+    static std::unordered_map<std::string, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(name);
+    if (it != cache.end()) return it->second < 0 ? fallback : it->second;
+    const std::string key = std::string("FIMEX_AMD_") + name;
+    const char* v = std::getenv(key.c_str());
+    const int parsed = (v && *v) ? std::atoi(v) : -1;
+    cache[name] = parsed;
+    return parsed < 0 ? fallback : parsed;
+}
+
+namespace {
+
+int usable_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int usable = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    return usable;
+}
+
+}  // namespace
+
+int current_device_checked()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        throw Error("no HIP device: fimex_amd has no CPU fallback, an MI355X (gfx950) is required");
+    }
+    int dev = 0;
+    FA_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FA_HIP(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        throw Error(std::string("device is ") + prop.gcnArchName + ", the kernels are built for gfx950 only");
+    return dev;
+}
+
+void require_current_device(int planDevice)
+{
+    int dev = 0;
+    FA_HIP(hipGetDevice(&dev));
+    FA_REQUIRE(dev == planDevice, "plan lives on device " + std::to_string(planDevice) +
+                                      " but the calling thread's current device is " + std::to_string(dev));
+}
+
+namespace {
+
+bool is_backward(int funcType)
+{
+    return funcType == FIMEX_AMD_INTERPOL_NEAREST_NEIGHBOR || funcType == FIMEX_AMD_INTERPOL_BILINEAR ||
+           funcType == FIMEX_AMD_INTERPOL_BICUBIC || funcType == FIMEX_AMD_INTERPOL_COORD_NN ||
+           funcType == FIMEX_AMD_INTERPOL_COORD_NN_KD;
+}
+
+bool is_forward(int funcType)
+{
+    return funcType >= FIMEX_AMD_INTERPOL_FORWARD_SUM && funcType <= FIMEX_AMD_INTERPOL_FORWARD_UNDEF_MIN;
+}
+
+std::unique_ptr<fimex_amd_regrid_plan> new_plan(int funcType, size_t nPoints, size_t inX, size_t inY, size_t outX, size_t outY)
+{
+    // same failure as CachedInterpolation.cc:114 / CachedForwardInterpolation.cc:88
+    FA_REQUIRE(is_backward(funcType) || is_forward(funcType), "unknown interpolation function: " + std::to_string(funcType));
+    auto plan = std::make_unique<fimex_amd_regrid_plan>();
+    plan->funcType = funcType;
+    plan->inX = inX;
+    plan->inY = inY;
+    plan->outX = outX;
+    plan->outY = outY;
+    if (is_backward(funcType)) {
+        plan->kind = funcType == FIMEX_AMD_INTERPOL_BILINEAR ? PlanKind::Bilinear
+                   : funcType == FIMEX_AMD_INTERPOL_BICUBIC  ? PlanKind::Bicubic
+                                                             : PlanKind::Nearest;
+        FA_REQUIRE(nPoints == outX * outY, "backward plans need one position per output cell (outX*outY)");
+    } else {
+        plan->kind = PlanKind::Forward;
+        const int k = (funcType - FIMEX_AMD_INTERPOL_FORWARD_SUM) % 5;
+        plan->aggregate = static_cast<Aggregate>(k);  // sum, mean, median, max, min
+        plan->undefAggr = funcType >= FIMEX_AMD_INTERPOL_FORWARD_UNDEF_SUM;
+        FA_REQUIRE(nPoints == inX * inY, "forward plans need one position per input cell (inX*inY)");
+    }
+    plan->device = current_device_checked();
+    plan->info.funcType = funcType;
+    plan->info.device = plan->device;
+    plan->info.inX = inX;
+    plan->info.inY = inY;
+    plan->info.outX = outX;
+    plan->info.outY = outY;
+    return plan;
+}
+
+void build_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+{
+    if (plan.kind == PlanKind::Forward) build_forward_plan(plan, d_px, d_py, stream);
+    else build_backward_plan(plan, d_px, d_py, stream);
+}
+
+void apply_device(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    if (plan.kind == PlanKind::Forward) launch_forward_apply(plan, d_in, nz, d_out, stream);
+    else launch_backward_apply(plan, d_in, nz, d_out, stream);
+}
+
+// host <-> device round trip shared by the in-place *_host entry points
+template <typename F>
+void with_device_copy(float* h, size_t n, hipStream_t stream, F&& body)
+{
+    DeviceArray<float> d(n);
+    FA_HIP(hipMemcpyAsync(d.get(), h, n * sizeof(float), hipMemcpyHostToDevice, stream));
+    body(d.get());
+    FA_HIP(hipMemcpyAsync(h, d.get(), n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+}
+
+}  // namespace
+}  // namespace fimex_amd
+
+using namespace fimex_amd;
+
+extern "C" {
+
+const char* fimex_amd_last_error(void) { return g_lastError.c_str(); }
+
+int fimex_amd_abi_version(void) { return 100; }
+
+int fimex_amd_device_count(void) { return usable_device_count(); }
+
+int fimex_amd_set_device(int ordinal)
+{
+    return c_guard([&] {
+        FA_HIP(hipSetDevice(ordinal));
+        (void)current_device_checked();
+    });
+}
+
+int fimex_amd_regrid_plan_create(int funcType, const double* px, const double* py, size_t nPoints, size_t inX, size_t inY,
+                                 size_t outX, size_t outY, fimex_amd_regrid_plan** out)
+{
+    return c_guard([&] {
+        FA_REQUIRE(out != nullptr, "plan output pointer is NULL");
+        *out = nullptr;
+        FA_REQUIRE(px != nullptr && py != nullptr, "position arrays are NULL");
+        auto plan = new_plan(funcType, nPoints, inX, inY, outX, outY);
+        ScopedStream stream;
+        DeviceArray<double> d_px(nPoints), d_py(nPoints);
+        FA_HIP(hipMemcpyAsync(d_px.get(), px, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        FA_HIP(hipMemcpyAsync(d_py.get(), py, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        build_plan(*plan, d_px.get(), d_py.get(), stream.get());
+        stream.sync();
+        *out = plan.release();
+    });
+}
+
+int fimex_amd_regrid_plan_create_device(int funcType, const double* d_px, const double* d_py, size_t nPoints, size_t inX,
+                                        size_t inY, size_t outX, size_t outY, void* stream, fimex_amd_regrid_plan** out)
+{
+    return c_guard([&] {
+        FA_REQUIRE(out != nullptr, "plan output pointer is NULL");
+        *out = nullptr;
+        FA_REQUIRE(d_px != nullptr && d_py != nullptr, "position arrays are NULL");
+        auto plan = new_plan(funcType, nPoints, inX, inY, outX, outY);
+        build_plan(*plan, d_px, d_py, as_stream(stream));
+        *out = plan.release();
+    });
+}
+
+int fimex_amd_regrid_plan_destroy(fimex_amd_regrid_plan* plan)
+{
+    return c_guard([&] {
+        if (!plan) return;
+        ScopedDevice dev(plan->device);
+        delete plan;
+    });
+}
+
+int fimex_amd_regrid_plan_info(const fimex_amd_regrid_plan* plan, fimex_amd_plan_info* info)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr && info != nullptr, "NULL argument");
+        *info = plan->info;
+    });
+}
+
+int fimex_amd_regrid_apply_host(const fimex_amd_regrid_plan* plan, const float* inData, size_t size, float* outData,
+                                size_t outCapacity, size_t* newSize)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr && newSize != nullptr, "NULL argument");
+        const size_t inLayer = plan->inX * plan->inY, outLayer = plan->outX * plan->outY;
+        const size_t nz = size / inLayer;  // CachedInterpolation.cc:121
+        *newSize = outLayer * nz;          // :122
+        if (outData == nullptr) return;    // size query
+        FA_REQUIRE(inData != nullptr || nz == 0, "inData is NULL");
+        FA_REQUIRE(outCapacity >= *newSize, "output buffer too small");
+        if (nz == 0) return;
+        ScopedDevice dev(plan->device);
+        ScopedStream stream;
+        DeviceArray<float> d_in(nz * inLayer), d_out(nz * outLayer);
+        FA_HIP(hipMemcpyAsync(d_in.get(), inData, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
+        apply_device(*plan, d_in.get(), nz, d_out.get(), stream.get());
+        FA_HIP(hipMemcpyAsync(outData, d_out.get(), d_out.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_regrid_apply_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        if (nz == 0) return;
+        FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
+        require_current_device(plan->device);
+        apply_device(*plan, d_in, nz, d_out, as_stream(stream));
+    });
+}
+
+int fimex_amd_vector_plan_create(const double* matrix, size_t ox, size_t oy, fimex_amd_vector_plan** out)
+{
+    return c_guard([&] {
+        FA_REQUIRE(out != nullptr, "plan output pointer is NULL");
+        *out = nullptr;
+        FA_REQUIRE(matrix != nullptr, "matrix is NULL");
+        auto plan = std::make_unique<fimex_amd_vector_plan>();
+        plan->device = current_device_checked();
+        plan->ox = ox;
+        plan->oy = oy;
+        build_vector_plan(*plan, matrix);
+        *out = plan.release();
+    });
+}
+
+int fimex_amd_vector_plan_destroy(fimex_amd_vector_plan* plan)
+{
+    return c_guard([&] {
+        if (!plan) return;
+        ScopedDevice dev(plan->device);
+        delete plan;
+    });
+}
+
+int fimex_amd_vector_reproject_values_host(const fimex_amd_vector_plan* plan, float* u, float* v, size_t size)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        const size_t layer = plan->ox * plan->oy;
+        const size_t oz = size / layer;  // CachedVectorReprojection.cc:41
+        if (oz == 0) return;
+        FA_REQUIRE(u != nullptr && v != nullptr, "NULL buffer");
+        ScopedDevice dev(plan->device);
+        ScopedStream stream;
+        const size_t n = oz * layer;
+        DeviceArray<float> d_u(n), d_v(n);
+        FA_HIP(hipMemcpyAsync(d_u.get(), u, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
+        FA_HIP(hipMemcpyAsync(d_v.get(), v, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
+        launch_vector_values(*plan, d_u.get(), d_v.get(), oz, stream.get());
+        FA_HIP(hipMemcpyAsync(u, d_u.get(), n * sizeof(float), hipMemcpyDeviceToHost, stream.get()));
+        FA_HIP(hipMemcpyAsync(v, d_v.get(), n * sizeof(float), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_vector_reproject_values_device(const fimex_amd_vector_plan* plan, float* d_u, float* d_v, size_t oz, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        if (oz == 0) return;
+        FA_REQUIRE(d_u != nullptr && d_v != nullptr, "NULL device buffer");
+        require_current_device(plan->device);
+        launch_vector_values(*plan, d_u, d_v, oz, as_stream(stream));
+    });
+}
+
+int fimex_amd_vector_reproject_direction_host(const fimex_amd_vector_plan* plan, float* angles, size_t size)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        const size_t layer = plan->ox * plan->oy;
+        const size_t oz = size / layer;  // CachedVectorReprojection.cc:52
+        if (oz == 0) return;
+        FA_REQUIRE(angles != nullptr, "NULL buffer");
+        ScopedDevice dev(plan->device);
+        ScopedStream stream;
+        with_device_copy(angles, oz * layer, stream.get(),
+                         [&](float* d) { launch_vector_direction(*plan, d, oz, stream.get()); });
+    });
+}
+
+int fimex_amd_vector_reproject_direction_device(const fimex_amd_vector_plan* plan, float* d_angles, size_t oz, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        if (oz == 0) return;
+        FA_REQUIRE(d_angles != nullptr, "NULL device buffer");
+        require_current_device(plan->device);
+        launch_vector_direction(*plan, d_angles, oz, as_stream(stream));
+    });
+}
+
+int fimex_amd_fill2d_host(size_t nx, size_t ny, size_t nz, float* field, float relaxCrit, float corrEff, size_t maxLoop,
+                          size_t* nChanged)
+{
+    return c_guard([&] {
+        if (nx * ny * nz == 0) return;
+        FA_REQUIRE(field != nullptr, "NULL buffer");
+        (void)current_device_checked();
+        ScopedStream stream;
+        with_device_copy(field, nx * ny * nz, stream.get(), [&](float* d) {
+            run_fill2d(nx, ny, nz, d, relaxCrit, corrEff, maxLoop, nChanged, stream.get());
+        });
+    });
+}
+
+int fimex_amd_fill2d_device(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
+                            size_t* nChanged, void* stream)
+{
+    return c_guard([&] {
+        if (nx * ny * nz == 0) return;
+        FA_REQUIRE(d_field != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        run_fill2d(nx, ny, nz, d_field, relaxCrit, corrEff, maxLoop, nChanged, as_stream(stream));
+    });
+}
+
+int fimex_amd_creepfill2d_host(size_t nx, size_t ny, size_t nz, float* field, unsigned short repeat, char setWeight,
+                               size_t* nChanged)
+{
+    return c_guard([&] {
+        if (nx * ny * nz == 0) return;
+        FA_REQUIRE(field != nullptr, "NULL buffer");
+        (void)current_device_checked();
+        ScopedStream stream;
+        with_device_copy(field, nx * ny * nz, stream.get(), [&](float* d) {
+            run_creepfill(nx, ny, nz, d, false, 0.f, repeat, setWeight, nChanged, stream.get());
+        });
+    });
+}
+
+int fimex_amd_creepfill2d_device(size_t nx, size_t ny, size_t nz, float* d_field, unsigned short repeat, char setWeight,
+                                 size_t* nChanged, void* stream)
+{
+    return c_guard([&] {
+        if (nx * ny * nz == 0) return;
+        FA_REQUIRE(d_field != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        run_creepfill(nx, ny, nz, d_field, false, 0.f, repeat, setWeight, nChanged, as_stream(stream));
+    });
+}
+
+int fimex_amd_creepfillval2d_host(size_t nx, size_t ny, size_t nz, float* field, float defaultVal, unsigned short repeat,
+                                  char setWeight, size_t* nChanged)
+{
+    return c_guard([&] {
+        if (nx * ny * nz == 0) return;
+        FA_REQUIRE(field != nullptr, "NULL buffer");
+        (void)current_device_checked();
+        ScopedStream stream;
+        with_device_copy(field, nx * ny * nz, stream.get(), [&](float* d) {
+            run_creepfill(nx, ny, nz, d, true, defaultVal, repeat, setWeight, nChanged, stream.get());
+        });
+    });
+}
+
+int fimex_amd_creepfillval2d_device(size_t nx, size_t ny, size_t nz, float* d_field, float defaultVal, unsigned short repeat,
+                                    char setWeight, size_t* nChanged, void* stream)
+{
+    return c_guard([&] {
+        if (nx * ny * nz == 0) return;
+        FA_REQUIRE(d_field != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        run_creepfill(nx, ny, nz, d_field, true, defaultVal, repeat, setWeight, nChanged, as_stream(stream));
+    });
+}
+
+int fimex_amd_bad2nan_device(float* d_data, size_t n, float badVal, void* stream)
+{
+    return c_guard([&] {
+        if (n == 0) return;
+        FA_REQUIRE(d_data != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        launch_bad2nan(d_data, n, badVal, as_stream(stream));
+    });
+}
+
+int fimex_amd_nan2bad_device(float* d_data, size_t n, float badVal, void* stream)
+{
+    return c_guard([&] {
+        if (n == 0) return;
+        FA_REQUIRE(d_data != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        launch_nan2bad(d_data, n, badVal, as_stream(stream));
+    });
+}
+
+int fimex_amd_points2position_device(double* d_points, size_t n, const double* axis, int num, int axis_type, void* stream)
+{
+    return c_guard([&] {
+        if (n == 0) return;
+        FA_REQUIRE(d_points != nullptr && axis != nullptr, "NULL argument");
+        (void)current_device_checked();
+        launch_points2position(d_points, n, axis, num, axis_type, as_stream(stream));
+    });
+}
+
+}  // extern "C"

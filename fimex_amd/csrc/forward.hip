@@ -1,0 +1,310 @@
+// Forward-mapping regrid (bucket reductions) for gfx950.
+//
+// Replaces CachedForwardInterpolation (src/CachedForwardInterpolation.cc:38-131): the reference
+// scans the source slice and push_back()s every value into a std::vector per target cell, then
+// aggregates each vector (sum / mean / median / max / min).  Here the scatter is inverted once,
+// at plan creation, into a CSR list of source cells per target cell, kept in source scan order;
+// the apply kernel is then a gather with no atomics and no allocation, and sums add in exactly the
+// reference's order (bit-identical results).
+//
+// Two apply paths, chosen per plan from its largest bucket:
+//  * lane-per-target: one lane walks its bucket; ZC slices are reduced together so that the CSR
+//    entries are read once per ZC slices;
+//  * wave-per-target (large buckets): the 64 lanes load 64 bucket entries at a time (coalesced
+//    index reads), a ballot drops undefined values, and the reduction is finished across the wave
+//    (shuffle reduction for max / min, ordered lane scan for sum / mean so that the reference's
+//    left-to-right float additions are kept).
+#include "plan.hpp"
+
+#include <vector>
+
+namespace fimex_amd {
+
+namespace {
+
+__device__ __forceinline__ float undefined_f() { return __uint_as_float(0x7fc00000u); }
+
+// RoundAndClamp(0, n-1, -1), src/Utils.cc:42-58 (round(): half away from zero)
+__device__ __forceinline__ int64_t round_clamp(double d, int64_t n)
+{
+    if (!(fabs(d) < 1073741824.0)) return -1;  // NaN / inf / beyond int: invalid
+    const int64_t r = (int64_t)round(d);
+    return (r >= 0 && r < n) ? r : -1;
+}
+
+// target cell of every source cell, src/CachedForwardInterpolation.cc:72-73 + :104-107
+__global__ void __launch_bounds__(kBlock) forward_targets(const double* __restrict__ px, const double* __restrict__ py,
+                                                          uint32_t nIn, int64_t outX, int64_t outY, uint32_t* __restrict__ tgt)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nIn) return;
+    const int64_t tx = round_clamp(px[i], outX);
+    const int64_t ty = round_clamp(py[i], outY);
+    tgt[i] = (tx >= 0 && ty >= 0) ? (uint32_t)(ty * outX + tx) : kInvalidPos;
+}
+
+struct FwdArgs {
+    const float* in;
+    float* out;
+    const uint32_t* offsets;
+    const uint32_t* src;
+    uint32_t nOut;
+    size_t inLayer;
+    uint32_t nz;
+    uint32_t zPerBlock;
+};
+
+template <bool UNDEF>
+__device__ __forceinline__ bool keep(float v) { return UNDEF || !isnan(v); }
+
+// sum / mean / max / min over one bucket, ZC slices at a time, one lane per target cell
+template <int KIND, bool UNDEF, int ZC>
+__global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= a.nOut) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
+    for (uint32_t z = z0; z < z1; z += ZC) {
+        const float* src = a.in + (size_t)z * a.inLayer;
+        // slices past the end of the chunk re-read the last one (results dropped): no branch in the gather loop
+        size_t koff[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) koff[k] = (size_t)min((uint32_t)k, z1 - 1 - z) * a.inLayer;
+        float acc[ZC];
+        uint32_t cnt[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; cnt[k] = 0; }
+        for (uint32_t j = b; j < e; ++j) {
+            const uint32_t i = a.src[j];
+            float v[ZC];
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) v[k] = src[koff[k] + i];
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) {
+                if (keep<UNDEF>(v[k])) {
+                    if (KIND == 0 || KIND == 1) acc[k] = acc[k] + v[k];                        // std::accumulate(.., 0.f)
+                    else if (KIND == 3) { if (cnt[k] == 0 || acc[k] < v[k]) acc[k] = v[k]; }   // std::max_element
+                    else { if (cnt[k] == 0 || v[k] < acc[k]) acc[k] = v[k]; }                  // std::min_element
+                    cnt[k]++;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) {
+            if (z + k < z1) {
+                float r = undefined_f();                             // empty bucket, :123-124
+                if (cnt[k] != 0) r = (KIND == 1) ? acc[k] / (float)cnt[k] : acc[k];  // aggrMean: sum / size()
+                __builtin_nontemporal_store(r, a.out + (size_t)(z + k) * a.nOut + t);
+            }
+        }
+    }
+}
+
+// median: value of rank size()/2 (std::nth_element, :49-53), by rank counting -- no scratch memory,
+// any bucket size; buckets are short in practice (DESIGN.md gives the occupancy histogram)
+template <bool UNDEF>
+__global__ void __launch_bounds__(kBlock) forward_apply_median(FwdArgs a)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= a.nOut) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
+    for (uint32_t z = z0; z < z1; ++z) {
+        const float* src = a.in + (size_t)z * a.inLayer;
+        uint32_t n = 0;
+        bool anyNan = false;
+        for (uint32_t j = b; j < e; ++j) {
+            const float v = src[a.src[j]];
+            if (isnan(v)) anyNan = true;
+            if (keep<UNDEF>(v)) n++;
+        }
+        float r = undefined_f();
+        // a NaN inside an "undef" bucket: the reference's nth_element result is implementation-defined
+        // (comparator not a strict weak order); the documented intent (value + undef = undef) is kept
+        if (n != 0 && !(UNDEF && anyNan)) {
+            const uint32_t want = n / 2;
+            for (uint32_t j = b; j < e; ++j) {
+                const float v = src[a.src[j]];
+                if (!keep<UNDEF>(v)) continue;
+                uint32_t less = 0, equalBefore = 0;
+                for (uint32_t q = b; q < e; ++q) {
+                    const float w = src[a.src[q]];
+                    if (!keep<UNDEF>(w)) continue;
+                    less += (w < v);
+                    equalBefore += (w == v && q < j);
+                }
+                if (less + equalBefore == want) { r = v; break; }
+            }
+        }
+        __builtin_nontemporal_store(r, a.out + (size_t)z * a.nOut + t);
+    }
+}
+
+// ---- wave-per-target path -------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(v, d, kWave); v = (v < o) ? o : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(v, d, kWave); v = (o < v) ? o : v; }
+    return v;
+}
+
+// one wave per target cell; 4 targets per workgroup
+template <int KIND, bool UNDEF>
+__global__ void __launch_bounds__(kBlock) forward_apply_wave(FwdArgs a)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= a.nOut) return;  // wave-uniform
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
+    for (uint32_t z = z0; z < z1; ++z) {
+        const float* src = a.in + (size_t)z * a.inLayer;
+        float acc = 0.f;       // running result, identical in every lane
+        uint32_t cnt = 0;
+        bool firstNan = false;  // max/min with UNDEF: a NaN in first position sticks (std::max_element)
+        for (uint32_t base = b; base < e; base += kWave) {
+            const uint32_t j = base + lane;
+            const bool inRange = j < e;
+            const float v = inRange ? src[a.src[j]] : 0.f;
+            const bool valid = inRange && keep<UNDEF>(v);
+            const unsigned long long mask = __ballot(valid);
+            if (mask == 0) continue;
+            if (KIND == 0 || KIND == 1) {
+                // ordered sum: fold the surviving lanes left to right, as std::accumulate does
+                unsigned long long m = mask;
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    acc = acc + __shfl(v, l, kWave);
+                    m &= m - 1;
+                }
+            } else {
+                if (UNDEF && cnt == 0) {
+                    const int l0 = __ffsll((long long)mask) - 1;
+                    firstNan = isnan(__shfl(v, l0, kWave));
+                }
+                // NaNs after the first position never win a "<" comparison: neutralise them
+                const bool usableV = valid && !isnan(v);
+                if (KIND == 3) {
+                    const float m = wave_max(usableV ? v : -INFINITY);
+                    if (__ballot(usableV)) acc = (cnt == 0 || acc < m) ? m : acc;
+                } else {
+                    const float m = wave_min(usableV ? v : INFINITY);
+                    if (__ballot(usableV)) acc = (cnt == 0 || m < acc) ? m : acc;
+                }
+            }
+            cnt += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0) {
+            float r = undefined_f();
+            if (cnt != 0) {
+                if (KIND == 1) r = acc / (float)cnt;
+                else if ((KIND == 3 || KIND == 4) && firstNan) r = undefined_f();
+                else r = acc;
+            }
+            a.out[(size_t)z * a.nOut + t] = r;
+        }
+    }
+}
+
+template <int KIND, bool UNDEF>
+void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, hipStream_t stream)
+{
+    if (wavePath) {
+        dim3 g((uint32_t)ceil_div(a.nOut, kBlock / kWave), grid.y, 1);
+        forward_apply_wave<KIND, UNDEF><<<g, kBlock, 0, stream>>>(a);
+    } else {
+        forward_apply_lane<KIND, UNDEF, 4><<<grid, kBlock, 0, stream>>>(a);
+    }
+}
+
+}  // namespace
+
+void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+{
+    const size_t nIn = plan.inX * plan.inY, nOut = plan.outX * plan.outY;
+    FA_REQUIRE(nIn > 0 && nIn <= kMaxSliceCells, "input grid must have between 1 and 2^30-1 cells per slice");
+    FA_REQUIRE(nOut > 0 && nOut <= 0x7FFFFFFFu, "output grid must have between 1 and 2^31-1 cells");
+    DeviceArray<uint32_t> d_tgt(nIn);
+    forward_targets<<<dim3((uint32_t)ceil_div(nIn, kBlock)), kBlock, 0, stream>>>(
+        d_px, d_py, (uint32_t)nIn, (int64_t)plan.outX, (int64_t)plan.outY, d_tgt.get());
+    FA_HIP(hipGetLastError());
+    std::vector<uint32_t> tgt(nIn);
+    FA_HIP(hipMemcpyAsync(tgt.data(), d_tgt.get(), nIn * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+
+    // stable counting sort by target: buckets keep source scan order (= the reference's push_back order)
+    std::vector<uint32_t> offsets(nOut + 1, 0);
+    size_t mapped = 0;
+    for (size_t i = 0; i < nIn; ++i)
+        if (tgt[i] != kInvalidPos) { offsets[tgt[i] + 1]++; mapped++; }
+    size_t maxBucket = 0, empty = 0;
+    for (size_t t = 0; t < nOut; ++t) {
+        if (offsets[t + 1] > maxBucket) maxBucket = offsets[t + 1];
+        if (offsets[t + 1] == 0) empty++;
+        offsets[t + 1] += offsets[t];
+    }
+    std::vector<uint32_t> src(mapped ? mapped : 1);
+    {
+        std::vector<uint32_t> cursor(offsets.begin(), offsets.end() - 1);
+        for (size_t i = 0; i < nIn; ++i)
+            if (tgt[i] != kInvalidPos) src[cursor[tgt[i]]++] = (uint32_t)i;
+    }
+    plan.offsets.allocate(nOut + 1);
+    plan.src.allocate(src.size());
+    FA_HIP(hipMemcpyAsync(plan.offsets.get(), offsets.data(), (nOut + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipMemcpyAsync(plan.src.get(), src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    plan.info.planBytes = (nOut + 1) * sizeof(uint32_t) + mapped * sizeof(uint32_t);
+    plan.info.undefinedCells = empty;
+    plan.info.maxBucket = maxBucket;
+    plan.info.mappedSourceCells = mapped;
+}
+
+void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    if (nz == 0) return;
+    FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
+    FwdArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.offsets = plan.offsets.get();
+    a.src = plan.src.get();
+    a.nOut = (uint32_t)(plan.outX * plan.outY);
+    a.inLayer = plan.inX * plan.inY;
+    a.nz = (uint32_t)nz;
+    uint32_t zpb = (uint32_t)tuning("FWD_ZPB", 8);
+    if (zpb > nz) zpb = (uint32_t)nz;
+    a.zPerBlock = zpb;
+    const size_t chunks = ceil_div(nz, (size_t)zpb);
+    FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
+    const dim3 grid((uint32_t)ceil_div(a.nOut, kBlock), (uint32_t)chunks, 1);
+    // mean bucket length decides: long buckets are reduced by a whole wave
+    const size_t nonEmpty = a.nOut - plan.info.undefinedCells;
+    const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
+    int waveMode = tuning("FWD_WAVE", -1);
+    const bool wavePath = (waveMode < 0) ? (meanBucket >= 32.0) : (waveMode != 0);
+    const bool u = plan.undefAggr;
+    switch (plan.aggregate) {
+    case Aggregate::Sum: u ? launch_kind<0, true>(a, grid, wavePath, stream) : launch_kind<0, false>(a, grid, wavePath, stream); break;
+    case Aggregate::Mean: u ? launch_kind<1, true>(a, grid, wavePath, stream) : launch_kind<1, false>(a, grid, wavePath, stream); break;
+    case Aggregate::Max: u ? launch_kind<3, true>(a, grid, wavePath, stream) : launch_kind<3, false>(a, grid, wavePath, stream); break;
+    case Aggregate::Min: u ? launch_kind<4, true>(a, grid, wavePath, stream) : launch_kind<4, false>(a, grid, wavePath, stream); break;
+    case Aggregate::Median:
+        if (u) forward_apply_median<true><<<grid, kBlock, 0, stream>>>(a);
+        else forward_apply_median<false><<<grid, kBlock, 0, stream>>>(a);
+        break;
+    }
+    FA_HIP(hipGetLastError());
+}
+
+}  // namespace fimex_amd

@@ -1,0 +1,90 @@
+// Regrid and rotation plans as they live in HBM.
+//
+// The reference keeps, per output cell, two doubles (fractional source position,
+// include/fimex/CachedInterpolation.h:108-109) and re-derives floor / fraction /
+// border class for every cell of every call.  Here that derivation runs once, on the
+// GPU, when the plan is created; the apply kernels read a compact structure-of-arrays
+// form that reproduces the reference's arithmetic bit for bit:
+//
+//   nearest   pos[n]            u32  source offset inside a slice, kInvalidPos = undefined
+//   bilinear  pos[n], xf[n], yf[n]   u32 + 2 x f32.  xf/yf are the fractions already rounded
+//             to float exactly as src/interpolation.c:885,888 does.  A set sign bit in xf
+//             (yf) marks "nearest neighbour in x (y)", i.e. the border branches of
+//             interpolation.c:903-948; pos then already points at the rounded cell.
+//   bicubic   pos[n], xfd[n], yfd[n] u32 + 2 x f64 (double fractions, interpolation.c:971,973);
+//             pos is the (x0-1, y0-1) corner of the 4x4 stencil.
+//   forward   offsets[nOut+1], src[nMapped]   CSR inverse of the reference's per-source-cell
+//             target index (src/CachedForwardInterpolation.cc:72-73), buckets in source scan
+//             order so that sums add in the reference's push_back order.
+#pragma once
+
+#include "common.hpp"
+
+namespace fimex_amd {
+
+constexpr uint32_t kInvalidPos = 0xFFFFFFFFu;
+// source slices are addressed with 32-bit cell offsets (and 32-bit byte offsets in the kernels)
+constexpr size_t kMaxSliceCells = (size_t(1) << 30) - 1;
+
+enum class PlanKind { Nearest, Bilinear, Bicubic, Forward };
+
+enum class Aggregate : int { Sum = 0, Mean = 1, Median = 2, Max = 3, Min = 4 };
+
+}  // namespace fimex_amd
+
+struct fimex_amd_regrid_plan {
+    int funcType = 0;
+    int device = 0;
+    fimex_amd::PlanKind kind = fimex_amd::PlanKind::Nearest;
+    size_t inX = 0, inY = 0, outX = 0, outY = 0;
+
+    // backward plans
+    fimex_amd::DeviceArray<uint32_t> pos;
+    fimex_amd::DeviceArray<float> xf, yf;
+    fimex_amd::DeviceArray<double> xfd, yfd;
+
+    // forward plans
+    fimex_amd::Aggregate aggregate = fimex_amd::Aggregate::Sum;
+    bool undefAggr = false;
+    fimex_amd::DeviceArray<uint32_t> offsets, src;
+
+    fimex_amd_plan_info info{};
+};
+
+struct fimex_amd_vector_plan {
+    int device = 0;
+    size_t ox = 0, oy = 0;
+    fimex_amd::DeviceArray<double2> cossin;  // (m0, m1) of the reference matrix
+    fimex_amd::DeviceArray<double> phi;      // m3
+};
+
+namespace fimex_amd {
+
+// regrid.hip
+void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
+void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+
+// forward.hip
+void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
+void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+
+// vector.hip
+void build_vector_plan(fimex_amd_vector_plan& plan, const double* h_matrix);
+void launch_vector_values(const fimex_amd_vector_plan& plan, float* d_u, float* d_v, size_t oz, hipStream_t stream);
+void launch_vector_direction(const fimex_amd_vector_plan& plan, float* d_angles, size_t oz, hipStream_t stream);
+
+// convert.hip
+void launch_bad2nan(float* d, size_t n, float bad, hipStream_t stream);
+void launch_nan2bad(float* d, size_t n, float bad, hipStream_t stream);
+void launch_points2position(double* d_points, size_t n, const double* h_axis, int num, int axisType, hipStream_t stream);
+
+// fill.hip
+void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
+                size_t* h_nChanged, hipStream_t stream);
+void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefault, float defaultVal,
+                   unsigned short repeat, char setWeight, size_t* h_nChanged, hipStream_t stream);
+
+// tuning knobs read once from the environment (FIMEX_AMD_<NAME>), for bench sweeps
+int tuning(const char* name, int fallback);
+
+}  // namespace fimex_amd

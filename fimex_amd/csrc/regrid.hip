@@ -1,0 +1,454 @@
+// Backward-mapping regrid for gfx950: plan classification and the nearest / bilinear /
+// bicubic apply kernels.
+//
+// Replaces the per-cell function-pointer loop of CachedInterpolation::interpolateValues
+// (src/CachedInterpolation.cc:118-147) around mifi_get_values_f / _bilinear_f / _bicubic_f
+// (src/interpolation.c:862-1028).
+//
+// Mapping to the machine (HBM-bound gather, no MFMA):
+//  * one lane per output cell, 256-lane workgroups over 256 consecutive output cells, so every
+//    store instruction of a wave writes 256 contiguous bytes and neighbouring lanes gather from
+//    neighbouring source cells (the same few 128-B lines);
+//  * the z loop (time x level slices) runs inside the lane: the plan entry is read once and kept
+//    in registers, and ZC slices are in flight per lane (4*ZC independent loads for bilinear)
+//    to cover HBM latency;
+//  * workgroups are dealt round-robin over the 8 XCDs, each with a private L2; the tile index is
+//    remapped so that one XCD owns a contiguous band of output rows and the source rows shared by
+//    vertically adjacent tiles are fetched into one L2 only;
+//  * outputs are written once and never re-read: non-temporal stores keep them out of the way of
+//    the source lines in L2.
+//
+// Built with -ffp-contract=off: every multiply and add below is a separate IEEE operation in
+// the same type and order as the reference, so results are bit-identical to the CPU path.
+#include "plan.hpp"
+
+namespace fimex_amd {
+
+namespace {
+
+__device__ __forceinline__ float undefined_f() { return __uint_as_float(0x7fc00000u); }  // MIFI_UNDEFINED_F
+
+// coordinates beyond this, NaN or inf are "outside" (the reference casts them to int: undefined behaviour)
+__device__ __forceinline__ bool usable(double x, double y)
+{
+    const double lim = 1073741824.0;
+    return (fabs(x) < lim) && (fabs(y) < lim);  // false for NaN
+}
+
+struct PlanCounters {
+    unsigned long long undefined;
+    unsigned long long border;
+};
+
+// ---------------------------------------------------------------- plan classification
+// src/interpolation.c:864-868
+__global__ void __launch_bounds__(kBlock) classify_nearest(const double* __restrict__ px, const double* __restrict__ py,
+                                                           uint32_t n, int64_t ix, int64_t iy,
+                                                           uint32_t* __restrict__ pos, PlanCounters* counters)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double x = px[i], y = py[i];
+    uint32_t p = kInvalidPos;
+    if (usable(x, y)) {
+        const int64_t rx = (int64_t)round(x);  // lround: half away from zero
+        const int64_t ry = (int64_t)round(y);
+        if (rx >= 0 && rx < ix && ry >= 0 && ry < iy) p = (uint32_t)(ry * ix + rx);
+    }
+    pos[i] = p;
+    if (p == kInvalidPos) atomicAdd(&counters->undefined, 1ull);
+}
+
+// src/interpolation.c:883-954 without the z loops
+__global__ void __launch_bounds__(kBlock) classify_bilinear(const double* __restrict__ px, const double* __restrict__ py,
+                                                            uint32_t n, int64_t ix, int64_t iy,
+                                                            uint32_t* __restrict__ pos, float* __restrict__ xf,
+                                                            float* __restrict__ yf, PlanCounters* counters)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double x = px[i], y = py[i];
+    uint32_t p = kInvalidPos;
+    float fx = 0.f, fy = 0.f;
+    bool border = false;
+    if (usable(x, y)) {
+        const double flx = floor(x), fly = floor(y);
+        const int64_t x0 = (int64_t)flx, y0 = (int64_t)fly;
+        fx = (float)(x - flx);  // :885, double difference rounded to float
+        fy = (float)(y - fly);  // :888
+        const bool xlin = (0 <= x0) && (x0 + 1 < ix);
+        const bool ylin = (0 <= y0) && (y0 + 1 < iy);
+        if (xlin && ylin) {
+            p = (uint32_t)(y0 * ix + x0);
+        } else if (xlin) {
+            const int64_t ry = (int64_t)round(y);  // :904
+            if (0 <= ry && ry < iy) { p = (uint32_t)(ry * ix + x0); fy = -1.f; border = true; }
+        } else {
+            const int64_t rx = (int64_t)round(x);  // :922
+            if (0 <= rx && rx < ix) {
+                if (ylin) {
+                    p = (uint32_t)(y0 * ix + rx); fx = -1.f; border = true;
+                } else {
+                    const int64_t ry = (int64_t)round(y);  // :935
+                    // the reference tests "ry <= iy" (:936) and then reads past the slice; undefined here
+                    if (0 <= ry && ry < iy) { p = (uint32_t)(ry * ix + rx); fx = -1.f; fy = -1.f; border = true; }
+                }
+            }
+        }
+    }
+    pos[i] = p;
+    xf[i] = fx;
+    yf[i] = fy;
+    if (p == kInvalidPos) atomicAdd(&counters->undefined, 1ull);
+    if (border) atomicAdd(&counters->border, 1ull);
+}
+
+// src/interpolation.c:970-976
+__global__ void __launch_bounds__(kBlock) classify_bicubic(const double* __restrict__ px, const double* __restrict__ py,
+                                                           uint32_t n, int64_t ix, int64_t iy,
+                                                           uint32_t* __restrict__ pos, double* __restrict__ xfd,
+                                                           double* __restrict__ yfd, PlanCounters* counters)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double x = px[i], y = py[i];
+    uint32_t p = kInvalidPos;
+    double fx = 0., fy = 0.;
+    if (usable(x, y)) {
+        const double flx = floor(x), fly = floor(y);
+        const int64_t x0 = (int64_t)flx, y0 = (int64_t)fly;
+        fx = x - flx;
+        fy = y - fly;
+        if ((1 <= x0) && (x0 + 2 < ix) && (1 <= y0) && (y0 + 2 < iy)) p = (uint32_t)((y0 - 1) * ix + (x0 - 1));
+    }
+    pos[i] = p;
+    xfd[i] = fx;
+    yfd[i] = fy;
+    if (p == kInvalidPos) atomicAdd(&counters->undefined, 1ull);
+}
+
+// ------------------------------------------------------------------------ apply kernels
+struct ApplyArgs {
+    const float* in;
+    float* out;
+    uint32_t nOut;         // cells per output slice
+    uint32_t ix;           // source row length
+    size_t inLayer;        // cells per source slice
+    uint32_t nz;
+    uint32_t zPerBlock;    // slices handled by one workgroup (blockIdx.y selects the chunk)
+    uint32_t nTiles;       // workgroup-sized tiles per slice
+    uint32_t tilesPerXcd;  // ceil(nTiles / 8)
+};
+
+// blockIdx.x -> tile so that each XCD (blockIdx.x % 8 under round-robin dispatch) works on a
+// contiguous band of the output.  Placement only affects speed, never results.
+__device__ __forceinline__ bool tile_cell(const ApplyArgs& a, uint32_t& cell)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = (b % kXcds) * a.tilesPerXcd + b / kXcds;
+    if (tile >= a.nTiles) return false;
+    cell = tile * kBlock + threadIdx.x;
+    return cell < a.nOut;
+}
+
+// Addressing: buffer instructions.  A 128-bit descriptor (4 SGPRs) is built per z chunk from
+// wave-uniform values; the per-lane part of an address is one 32-bit byte offset VGPR (plus an
+// immediate), the slice index goes into the scalar offset.  No 64-bit per-lane address arithmetic,
+// which keeps the register budget for loads in flight.  A chunk must span < 4 GiB (checked on the
+// host: kernels with ZC > 1 are only launched when ZC slices fit).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// outputs are written once and never re-read by this kernel: non-temporal (aux = 2)
+__device__ __forceinline__ void st_stream(rsrc_t r, uint32_t voff, uint32_t soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 2);
+}
+
+__device__ __forceinline__ void write_undefined(const ApplyArgs& a, uint32_t cell, uint32_t z0, uint32_t z1)
+{
+    const uint32_t outBytes = a.nOut * 4u;
+    const float* o = a.out + (size_t)z0 * a.nOut;
+    for (uint32_t z = z0; z < z1; ++z, o += a.nOut) st_stream(make_rsrc(o, outBytes), cell * 4u, 0, undefined_f());
+}
+
+template <int ZC>
+__global__ void __launch_bounds__(kBlock) nearest_apply(ApplyArgs a, const uint32_t* __restrict__ pos)
+{
+    uint32_t cell;
+    if (!tile_cell(a, cell)) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t p = pos[cell];
+    if (p == kInvalidPos) { write_undefined(a, cell, z0, z1); return; }
+    const uint32_t pb = p * 4u, cb = cell * 4u;
+    const uint32_t inBytes = (uint32_t)a.inLayer * 4u, outBytes = a.nOut * 4u;
+    const float* src = a.in + (size_t)z0 * a.inLayer;
+    const float* o = a.out + (size_t)z0 * a.nOut;
+    uint32_t z = z0;
+    for (; z + ZC <= z1; z += ZC) {
+        const rsrc_t rs = make_rsrc(src, inBytes * ZC), ro = make_rsrc(o, outBytes * ZC);
+        float v[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) v[k] = ld(rs, pb, inBytes * k);
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) st_stream(ro, cb, outBytes * k, v[k]);
+        src += (size_t)ZC * a.inLayer;
+        o += (size_t)ZC * a.nOut;
+    }
+    for (; z < z1; ++z, src += a.inLayer, o += a.nOut)
+        st_stream(make_rsrc(o, outBytes), cb, 0, ld(make_rsrc(src, inBytes), pb, 0));
+}
+
+// interior cell, src/interpolation.c:899-900
+__device__ __forceinline__ float bilinear_point(float s00, float s01, float s10, float s11, float xf, float yf)
+{
+    return (1.f - yf) * ((1.f - xf) * s00 + xf * s01) + yf * ((1.f - xf) * s10 + xf * s11);
+}
+
+template <int ZC>
+__global__ void __launch_bounds__(kBlock) bilinear_apply(ApplyArgs a, const uint32_t* __restrict__ pos,
+                                                         const float* __restrict__ xfrac, const float* __restrict__ yfrac)
+{
+    uint32_t cell;
+    if (!tile_cell(a, cell)) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t p = pos[cell];
+    const float xf = xfrac[cell], yf = yfrac[cell];
+    if (p == kInvalidPos) { write_undefined(a, cell, z0, z1); return; }
+    const bool nnx = (__float_as_uint(xf) >> 31) != 0;
+    const bool nny = (__float_as_uint(yf) >> 31) != 0;
+    const uint32_t inBytes = (uint32_t)a.inLayer * 4u, outBytes = a.nOut * 4u;
+    const float* src = a.in + (size_t)z0 * a.inLayer;
+    const float* o = a.out + (size_t)z0 * a.nOut;
+    const uint32_t pb = p * 4u, cb = cell * 4u;
+    const uint32_t pb1 = pb + a.ix * 4u;  // the row below
+    if (!(nnx || nny)) {
+        uint32_t z = z0;
+        for (; z + ZC <= z1; z += ZC) {
+            const rsrc_t rs = make_rsrc(src, inBytes * ZC), ro = make_rsrc(o, outBytes * ZC);
+            float s00[ZC], s01[ZC], s10[ZC], s11[ZC];
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) {
+                s00[k] = ld(rs, pb, inBytes * k);
+                s01[k] = ld(rs, pb + 4u, inBytes * k);
+                s10[k] = ld(rs, pb1, inBytes * k);
+                s11[k] = ld(rs, pb1 + 4u, inBytes * k);
+            }
+#pragma unroll
+            for (int k = 0; k < ZC; ++k)
+                st_stream(ro, cb, outBytes * k, bilinear_point(s00[k], s01[k], s10[k], s11[k], xf, yf));
+            src += (size_t)ZC * a.inLayer;
+            o += (size_t)ZC * a.nOut;
+        }
+        for (; z < z1; ++z, src += a.inLayer, o += a.nOut) {
+            const rsrc_t rs = make_rsrc(src, inBytes);
+            st_stream(make_rsrc(o, outBytes), cb, 0,
+                      bilinear_point(ld(rs, pb, 0), ld(rs, pb + 4u, 0), ld(rs, pb1, 0), ld(rs, pb1 + 4u, 0), xf, yf));
+        }
+    } else {
+        // border branches of src/interpolation.c:903-948: a handful of cells on the rim of the domain
+        for (uint32_t z = z0; z < z1; ++z, src += a.inLayer, o += a.nOut) {
+            const rsrc_t rs = make_rsrc(src, inBytes);
+            const float s00 = ld(rs, pb, 0);
+            float r;
+            if (nnx && nny) r = s00;                                       // :939-942
+            else if (nny) r = (1.f - xf) * s00 + xf * ld(rs, pb + 4u, 0);  // :911
+            else r = (1 - yf) * s00 + (yf * ld(rs, pb1, 0));               // :931
+            st_stream(make_rsrc(o, outBytes), cb, 0, r);
+        }
+    }
+}
+
+// Keys kernel a = -0.5: rows of M/2 (src/interpolation.c:962-968), weights XM / MY (:977-1000)
+__device__ __forceinline__ void cubic_weights(double f, double w[4])
+{
+    const double M[4][4] = {{0.0, 1.0, 0.0, 0.0}, {-0.5, 0.0, 0.5, 0.0}, {1.0, -2.5, 2.0, -0.5}, {-0.5, 1.5, -1.5, 0.5}};
+    double X[4];
+    X[0] = 1;
+    X[1] = f;
+    X[2] = f * f;
+    X[3] = X[2] * f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += X[j] * M[j][i];
+        w[i] = s;
+    }
+}
+
+// one 4x4 stencil: XMF[i] = sum_j XM[j] * F[j][i] (:1015), out += XMF[i] * MY[i] into the float (:1005,1019)
+__device__ __forceinline__ float bicubic_point(const float f[4][4], const double XM[4], const double MY[4])
+{
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double xmf = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xmf += XM[j] * (double)f[i][j];
+        acc = (float)((double)acc + xmf * MY[i]);
+    }
+    return acc;
+}
+
+template <int ZC>
+__global__ void __launch_bounds__(kBlock) bicubic_apply(ApplyArgs a, const uint32_t* __restrict__ pos,
+                                                        const double* __restrict__ xfd, const double* __restrict__ yfd)
+{
+    uint32_t cell;
+    if (!tile_cell(a, cell)) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t p = pos[cell];
+    if (p == kInvalidPos) { write_undefined(a, cell, z0, z1); return; }
+    double XM[4], MY[4];
+    cubic_weights(xfd[cell], XM);
+    cubic_weights(yfd[cell], MY);
+    const uint32_t inBytes = (uint32_t)a.inLayer * 4u, outBytes = a.nOut * 4u;
+    const float* src = a.in + (size_t)z0 * a.inLayer;
+    const float* o = a.out + (size_t)z0 * a.nOut;
+    const uint32_t cb = cell * 4u;
+    uint32_t rowb[4];  // byte offsets of the four stencil rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowb[i] = (p + i * a.ix) * 4u;
+    uint32_t z = z0;
+    for (; z + ZC <= z1; z += ZC) {
+        const rsrc_t rs = make_rsrc(src, inBytes * ZC), ro = make_rsrc(o, outBytes * ZC);
+        float f[ZC][4][4];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[k][i][j] = ld(rs, rowb[i] + 4u * j, inBytes * k);
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) st_stream(ro, cb, outBytes * k, bicubic_point(f[k], XM, MY));
+        src += (size_t)ZC * a.inLayer;
+        o += (size_t)ZC * a.nOut;
+    }
+    for (; z < z1; ++z, src += a.inLayer, o += a.nOut) {
+        const rsrc_t rs = make_rsrc(src, inBytes);
+        float f[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[i][j] = ld(rs, rowb[i] + 4u * j, 0);
+        st_stream(make_rsrc(o, outBytes), cb, 0, bicubic_point(f, XM, MY));
+    }
+}
+
+ApplyArgs make_args(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, dim3& grid)
+{
+    ApplyArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.nOut = (uint32_t)(plan.outX * plan.outY);
+    a.ix = (uint32_t)plan.inX;
+    a.inLayer = plan.inX * plan.inY;
+    a.nz = (uint32_t)nz;
+    a.nTiles = (uint32_t)ceil_div(a.nOut, kBlock);
+    a.tilesPerXcd = (uint32_t)ceil_div(a.nTiles, kXcds);
+    // slices per workgroup: long enough to amortise the plan read, short enough that the grid
+    // still holds several waves of workgroups per CU
+    uint32_t zpb = (uint32_t)tuning("ZPB", 0);
+    if (zpb == 0) {
+        const size_t wantBlocks = 256 * 8 * 4;
+        size_t chunks = ceil_div(wantBlocks, (size_t)a.nTiles);
+        if (chunks > nz) chunks = nz;
+        if (chunks < 1) chunks = 1;
+        zpb = (uint32_t)ceil_div(nz, chunks);
+        const uint32_t zpbMax = (uint32_t)tuning("ZPB_MAX", 40);
+        if (zpb > zpbMax) zpb = zpbMax;
+    }
+    if (zpb > nz) zpb = (uint32_t)nz;
+    a.zPerBlock = zpb;
+    const size_t chunks = ceil_div(nz, (size_t)zpb);
+    FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
+    grid = dim3(a.tilesPerXcd * kXcds, (uint32_t)chunks, 1);
+    return a;
+}
+
+}  // namespace
+
+void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+{
+    const size_t n = plan.outX * plan.outY;
+    FA_REQUIRE(n > 0 && n <= kMaxSliceCells, "output grid must have between 1 and 2^30-1 cells per slice");
+    FA_REQUIRE(plan.inX > 0 && plan.inY > 0 && plan.inX * plan.inY <= kMaxSliceCells,
+               "input grid must have between 1 and 2^30-1 cells per slice");
+    DeviceArray<PlanCounters> counters(1);
+    FA_HIP(hipMemsetAsync(counters.get(), 0, sizeof(PlanCounters), stream));
+    const dim3 grid((uint32_t)ceil_div(n, kBlock));
+    plan.pos.allocate(n);
+    switch (plan.kind) {
+    case PlanKind::Nearest:
+        classify_nearest<<<grid, kBlock, 0, stream>>>(d_px, d_py, (uint32_t)n, (int64_t)plan.inX, (int64_t)plan.inY,
+                                                      plan.pos.get(), counters.get());
+        plan.info.planBytes = plan.pos.bytes();
+        break;
+    case PlanKind::Bilinear:
+        plan.xf.allocate(n);
+        plan.yf.allocate(n);
+        classify_bilinear<<<grid, kBlock, 0, stream>>>(d_px, d_py, (uint32_t)n, (int64_t)plan.inX, (int64_t)plan.inY,
+                                                       plan.pos.get(), plan.xf.get(), plan.yf.get(), counters.get());
+        plan.info.planBytes = plan.pos.bytes() + plan.xf.bytes() + plan.yf.bytes();
+        break;
+    case PlanKind::Bicubic:
+        plan.xfd.allocate(n);
+        plan.yfd.allocate(n);
+        classify_bicubic<<<grid, kBlock, 0, stream>>>(d_px, d_py, (uint32_t)n, (int64_t)plan.inX, (int64_t)plan.inY,
+                                                      plan.pos.get(), plan.xfd.get(), plan.yfd.get(), counters.get());
+        plan.info.planBytes = plan.pos.bytes() + plan.xfd.bytes() + plan.yfd.bytes();
+        break;
+    default:
+        throw Error("build_backward_plan: not a backward plan");
+    }
+    FA_HIP(hipGetLastError());
+    PlanCounters h{};
+    FA_HIP(hipMemcpyAsync(&h, counters.get(), sizeof(h), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    plan.info.undefinedCells = (size_t)h.undefined;
+    plan.info.borderCells = (size_t)h.border;
+}
+
+void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    if (nz == 0) return;
+    FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
+    dim3 grid;
+    const ApplyArgs a = make_args(plan, d_in, nz, d_out, grid);
+    // a chunk of ZC slices is addressed through one 32-bit buffer range: fall back to ZC = 1 for huge slices
+    const size_t sliceBytes = 4 * (a.inLayer > a.nOut ? a.inLayer : (size_t)a.nOut);
+    auto fits = [&](size_t zc) { return sliceBytes * zc <= 0xFFFFFFFFull; };
+    switch (plan.kind) {
+    case PlanKind::Nearest:
+        if (fits(16)) nearest_apply<16><<<grid, kBlock, 0, stream>>>(a, plan.pos.get());
+        else nearest_apply<1><<<grid, kBlock, 0, stream>>>(a, plan.pos.get());
+        break;
+    case PlanKind::Bilinear: {
+        const int zc = tuning("BILINEAR_ZC", 8);
+        if (zc >= 8 && fits(8)) bilinear_apply<8><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get());
+        else if (zc >= 4 && fits(4)) bilinear_apply<4><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get());
+        else bilinear_apply<1><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get());
+        break;
+    }
+    case PlanKind::Bicubic:
+        if (fits(2)) bicubic_apply<2><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xfd.get(), plan.yfd.get());
+        else bicubic_apply<1><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xfd.get(), plan.yfd.get());
+        break;
+    default:
+        throw Error("launch_backward_apply: not a backward plan");
+    }
+    FA_HIP(hipGetLastError());
+}
+
+}  // namespace fimex_amd

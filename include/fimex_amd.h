@@ -1,0 +1,191 @@
+/*
+ * fimex_amd.h -- C ABI of the MI355X regridding engine (libfimex_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of Fimex's CDMInterpolator
+ * (L1 + L2 of SURVEY.md): what a maintainer binds from the reference's C++ in
+ * place of the per-point mifi_* calls.  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference tree).  Plain pointers
+ * and sizes only; no C++ or torch types.
+ *
+ * Conventions (same as the reference's C kernels, include/fimex/mifi_constants.h:259-261):
+ *   return FIMEX_AMD_OK (1) or FIMEX_AMD_ERROR (-1); after an error
+ *   fimex_amd_last_error() returns a message for the calling thread.
+ *   Undefined values are IEEE NaN (mifi_constants.h:249-256).
+ *   Fields are C arrays [nz][ny][nx], x fastest (include/fimex/interpolation.h:423-426).
+ *
+ * *_host entry points take host pointers (the reference's boost::shared_array
+ * buffers), copy to the GPU, run the kernels and copy back; they are re-entrant
+ * and may be called concurrently from several threads on one plan, as the
+ * reference's writers do (src/NetCDF_CDMWriter.cc:749-753).
+ * *_device entry points take device pointers plus a hipStream_t (passed as
+ * void*; NULL = the default stream) and only enqueue work on that stream.
+ *
+ * There is no CPU fallback: every compute entry point fails with
+ * FIMEX_AMD_ERROR when no gfx950 device is usable.
+ */
+#ifndef FIMEX_AMD_H_
+#define FIMEX_AMD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIMEX_AMD_OK 1
+#define FIMEX_AMD_ERROR -1
+
+/* interpolation methods: values of enum mifi_interpol_method, include/fimex/mifi_constants.h:52-147 */
+#define FIMEX_AMD_INTERPOL_NEAREST_NEIGHBOR 0
+#define FIMEX_AMD_INTERPOL_BILINEAR 1
+#define FIMEX_AMD_INTERPOL_BICUBIC 2
+#define FIMEX_AMD_INTERPOL_COORD_NN 3
+#define FIMEX_AMD_INTERPOL_COORD_NN_KD 4
+#define FIMEX_AMD_INTERPOL_FORWARD_SUM 5
+#define FIMEX_AMD_INTERPOL_FORWARD_MEAN 6
+#define FIMEX_AMD_INTERPOL_FORWARD_MEDIAN 7
+#define FIMEX_AMD_INTERPOL_FORWARD_MAX 8
+#define FIMEX_AMD_INTERPOL_FORWARD_MIN 9
+#define FIMEX_AMD_INTERPOL_FORWARD_UNDEF_SUM 10
+#define FIMEX_AMD_INTERPOL_FORWARD_UNDEF_MEAN 11
+#define FIMEX_AMD_INTERPOL_FORWARD_UNDEF_MEDIAN 12
+#define FIMEX_AMD_INTERPOL_FORWARD_UNDEF_MAX 13
+#define FIMEX_AMD_INTERPOL_FORWARD_UNDEF_MIN 14
+
+/* axis types of mifi_points2position, include/fimex/mifi_constants.h:263-268 */
+#define FIMEX_AMD_PROJ_AXIS 0
+#define FIMEX_AMD_LONGITUDE 1
+#define FIMEX_AMD_LATITUDE 2
+
+/* ------------------------------------------------------------------ library */
+/** Message of the last error raised on the calling thread ("" if none). */
+const char* fimex_amd_last_error(void);
+/** ABI version of this header (major*100 + minor). */
+int fimex_amd_abi_version(void);
+/** Number of usable gfx950 devices (0 when there is none; never an error). */
+int fimex_amd_device_count(void);
+/** Device the calling thread creates plans on (hipSetDevice). */
+int fimex_amd_set_device(int ordinal);
+
+/* ------------------------------------------------------------- regrid plans */
+/**
+ * Opaque, immutable regrid plan resident in HBM.  Replaces the state of
+ * CachedInterpolation (include/fimex/CachedInterpolation.h:105-161: two
+ * std::vector<double> + a function pointer) and of CachedForwardInterpolation
+ * (src/CachedForwardInterpolation.h:37-59: two std::vector<int> + aggregator).
+ */
+typedef struct fimex_amd_regrid_plan fimex_amd_regrid_plan;
+
+/**
+ * Replaces the constructors CachedInterpolation::CachedInterpolation
+ * (src/CachedInterpolation.cc:93-116) and
+ * CachedForwardInterpolation::CachedForwardInterpolation
+ * (src/CachedForwardInterpolation.cc:62-90) -- same arguments minus the
+ * dimension names.
+ *
+ * funcType NEAREST_NEIGHBOR / BILINEAR / BICUBIC / COORD_NN / COORD_NN_KD:
+ *   backward plan; pointsOnXAxis/pointsOnYAxis hold, per OUTPUT cell
+ *   (nPoints == outX*outY), the fractional position in the input grid.
+ * funcType FORWARD_*: forward plan; the arrays hold, per INPUT cell
+ *   (nPoints == inX*inY), the fractional position in the output grid.
+ * Any other funcType fails ("unknown interpolation function", as
+ * CachedInterpolation.cc:114 / CachedForwardInterpolation.cc:88 throw).
+ * The arrays are host memory and are not referenced after the call returns.
+ */
+int fimex_amd_regrid_plan_create(int funcType,
+                                 const double* pointsOnXAxis, const double* pointsOnYAxis, size_t nPoints,
+                                 size_t inX, size_t inY, size_t outX, size_t outY,
+                                 fimex_amd_regrid_plan** plan);
+/** Same, with the two position arrays already in device memory (plan build stays on the GPU). */
+int fimex_amd_regrid_plan_create_device(int funcType,
+                                        const double* d_pointsOnXAxis, const double* d_pointsOnYAxis, size_t nPoints,
+                                        size_t inX, size_t inY, size_t outX, size_t outY,
+                                        void* stream, fimex_amd_regrid_plan** plan);
+int fimex_amd_regrid_plan_destroy(fimex_amd_regrid_plan* plan);
+
+typedef struct fimex_amd_plan_info {
+    int funcType;
+    int device;                /* HIP ordinal the plan lives on */
+    size_t inX, inY, outX, outY;
+    size_t planBytes;          /* bytes of plan one apply launch reads (B_plan of DESIGN.md) */
+    size_t undefinedCells;     /* backward: output cells that are NaN for every input; forward: empty buckets */
+    size_t borderCells;        /* backward bilinear: cells on a border branch (interpolation.c:903-948) */
+    size_t maxBucket;          /* forward: largest bucket (source cells per target) */
+    size_t mappedSourceCells;  /* forward: source cells that fall inside the target grid */
+} fimex_amd_plan_info;
+int fimex_amd_regrid_plan_info(const fimex_amd_regrid_plan* plan, fimex_amd_plan_info* info);
+
+/**
+ * Replaces CachedInterpolationInterface::interpolateValues
+ * (include/fimex/CachedInterpolation.h:67; src/CachedInterpolation.cc:118-147,
+ * src/CachedForwardInterpolation.cc:92-131).
+ * inData: host [size/(inX*inY)][inY][inX], not modified.
+ * outData: host buffer the caller owns (the reference allocates it itself,
+ * CachedInterpolation.cc:123); outCapacity in floats must be >= *newSize.
+ * *newSize = outX*outY*(size/(inX*inY)), as CachedInterpolation.cc:120-122.
+ * Pass outData == NULL to query *newSize only.
+ */
+int fimex_amd_regrid_apply_host(const fimex_amd_regrid_plan* plan,
+                                const float* inData, size_t size,
+                                float* outData, size_t outCapacity, size_t* newSize);
+/** Device-resident form: d_in [nz][inY][inX] -> d_out [nz][outY][outX], enqueued on stream. */
+int fimex_amd_regrid_apply_device(const fimex_amd_regrid_plan* plan,
+                                  const float* d_in, size_t nz, float* d_out, void* stream);
+
+/* ---------------------------------------------------------- vector rotation */
+/**
+ * Opaque rotation plan.  Replaces CachedVectorReprojection
+ * (include/fimex/CachedVectorReprojection.h:33-63): built from the same
+ * double[4*ox*oy] matrix (cos, sin, -sin, phi per cell, src/interpolation.c:429-432).
+ * The matrix is copied; a compact (cos,sin) / phi form is kept in HBM.
+ */
+typedef struct fimex_amd_vector_plan fimex_amd_vector_plan;
+int fimex_amd_vector_plan_create(const double* matrix, size_t ox, size_t oy, fimex_amd_vector_plan** plan);
+int fimex_amd_vector_plan_destroy(fimex_amd_vector_plan* plan);
+/** Replaces CachedVectorReprojection::reprojectValues (src/CachedVectorReprojection.cc:35-44) ->
+ *  mifi_vector_reproject_values_by_matrix_f (src/interpolation.c:790-812); u, v rotated in place. */
+int fimex_amd_vector_reproject_values_host(const fimex_amd_vector_plan* plan, float* u, float* v, size_t size);
+int fimex_amd_vector_reproject_values_device(const fimex_amd_vector_plan* plan, float* d_u, float* d_v, size_t oz, void* stream);
+/** Replaces CachedVectorReprojection::reprojectDirectionValues (src/CachedVectorReprojection.cc:46-55) ->
+ *  mifi_vector_reproject_direction_by_matrix_f (src/interpolation.c:814-835); degrees, in place. */
+int fimex_amd_vector_reproject_direction_host(const fimex_amd_vector_plan* plan, float* angles, size_t size);
+int fimex_amd_vector_reproject_direction_device(const fimex_amd_vector_plan* plan, float* d_angles, size_t oz, void* stream);
+
+/* ------------------------------------------------------ 2-D fill processes */
+/*
+ * Batch forms of the InterpolatorProcess2d implementations
+ * (include/fimex/CDMInterpolator.h:49-88) as driven by processArray_
+ * (src/CDMInterpolator.cc:136-159): every [ny][nx] slice of field[nz][ny][nx] is
+ * filled in place, independently.  nChanged: NULL or size_t[nz] receiving the
+ * per-slice count of undefined cells the reference returns through *nChanged.
+ */
+/** mifi_fill2d_f, include/fimex/interpolation.h:483, src/interpolation.c:1246-1376 */
+int fimex_amd_fill2d_host(size_t nx, size_t ny, size_t nz, float* field,
+                          float relaxCrit, float corrEff, size_t maxLoop, size_t* nChanged);
+int fimex_amd_fill2d_device(size_t nx, size_t ny, size_t nz, float* d_field,
+                            float relaxCrit, float corrEff, size_t maxLoop, size_t* nChanged, void* stream);
+/** mifi_creepfill2d_f, include/fimex/interpolation.h:505, src/interpolation.c:1495-1519 */
+int fimex_amd_creepfill2d_host(size_t nx, size_t ny, size_t nz, float* field,
+                               unsigned short repeat, char setWeight, size_t* nChanged);
+int fimex_amd_creepfill2d_device(size_t nx, size_t ny, size_t nz, float* d_field,
+                                 unsigned short repeat, char setWeight, size_t* nChanged, void* stream);
+/** mifi_creepfillval2d_f, include/fimex/interpolation.h:528, src/interpolation.c:1521-1537 */
+int fimex_amd_creepfillval2d_host(size_t nx, size_t ny, size_t nz, float* field, float defaultVal,
+                                  unsigned short repeat, char setWeight, size_t* nChanged);
+int fimex_amd_creepfillval2d_device(size_t nx, size_t ny, size_t nz, float* d_field, float defaultVal,
+                                    unsigned short repeat, char setWeight, size_t* nChanged, void* stream);
+
+/* ------------------------------------------------- edges of the path (a13) */
+/** mifi_bad2nanf / mifi_nanf2bad, src/interpolation.c:1775-1793, on n device floats in place. */
+int fimex_amd_bad2nan_device(float* d_data, size_t n, float badVal, void* stream);
+int fimex_amd_nan2bad_device(float* d_data, size_t n, float badVal, void* stream);
+
+/* ------------------------------------------------------- plan build helpers */
+/** mifi_points2position, include/fimex/interpolation.h:415, src/interpolation.c:148-217:
+ *  n device doubles (radians or metres) -> fractional axis indices, in place. axis: host, num entries. */
+int fimex_amd_points2position_device(double* d_points, size_t n, const double* axis, int num, int axis_type, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIMEX_AMD_H_ */

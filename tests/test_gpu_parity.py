@@ -1,0 +1,276 @@
+"""Parity of the HIP path (through the C ABI, include/fimex_amd.h) with the CPU oracle on the same
+seeded inputs.  Bar (BASELINE.json north_star): bit-exact for nearest / index methods, <= 1e-5
+relative for bilinear / bicubic / rotation.  The kernels are built with -ffp-contract=off and
+follow the reference's operation order, so every comparison below is in fact bit-exact on defined
+values with identical NaN positions; the 1e-5 bound is asserted as well where north_star names it.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    from fimex_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1, "no gfx950 device visible"
+    return capi
+
+
+def _rel_ok(got, want, tol=1e-5):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    ok = np.isfinite(want)
+    return np.all(np.abs(got[ok] - want[ok]) <= tol * np.abs(want[ok]) + 1e-30)
+
+
+BACKWARD = [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC, oracle.COORD_NN, oracle.COORD_NN_KD]
+
+
+@pytest.mark.parametrize("method", BACKWARD)
+@pytest.mark.parametrize("shape", [(37, 29, 41, 33, 3), (300, 200, 157, 211, 11), (64, 64, 256, 4, 1), (5, 4, 7, 6, 19)])
+def test_backward_methods_match_oracle(fa, method, shape):
+    inX, inY, outX, outY, nz = shape
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=100 + method)
+    f = cases.field(nz, inY, inX, seed=7 + method)
+    want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    got = plan.apply_host(f)
+    assert got.shape == want.shape
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert _rel_ok(got, want)
+    info = plan.info()
+    assert info["undefinedCells"] > 0  # the case overshoots the source on purpose
+    if method == oracle.BILINEAR:
+        assert info["borderCells"] > 0
+
+
+@pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
+@pytest.mark.parametrize("nz", [1, 2, 7, 8, 9, 16, 17, 41, 83])
+def test_backward_ragged_z_counts(fa, method, nz):
+    """z counts around the in-kernel unroll factors and the z-chunking of the grid."""
+    inX, inY, outX, outY = 120, 90, 100, 70
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=5)
+    f = cases.field(nz, inY, inX, seed=nz)
+    want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    got = fa.RegridPlan(method, px, py, inX, inY, outX, outY).apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+def test_backward_empty_and_query(fa):
+    px, py = cases.backward_positions(10, 8, 6, 5, seed=1, special=False)
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, 10, 8, 6, 5)
+    out = plan.apply_host(np.zeros((0, 8, 10), np.float32))
+    assert out.shape == (0, 5, 6)
+    # size not a multiple of the slice: trailing floats are ignored like CachedInterpolation.cc:121 (integer division)
+    f = cases.field(2, 8, 10, seed=3)
+    flat = np.concatenate([f.ravel(), np.ones(13, np.float32)])
+    got = plan.apply_host(flat)
+    assert cases.same(got, oracle.interpolate_values(oracle.BILINEAR, px, py, f, 10, 8, 6, 5))
+
+
+def test_unknown_method_fails_like_the_reference(fa):
+    px, py = cases.backward_positions(10, 8, 6, 5, seed=1, special=False)
+    with pytest.raises(fa.FimexAmdError, match="unknown interpolation function"):
+        fa.RegridPlan(99, px, py, 10, 8, 6, 5)
+    with pytest.raises(fa.FimexAmdError):
+        fa.RegridPlan(oracle.BILINEAR, px[:-1], py[:-1], 10, 8, 6, 5)
+
+
+def test_reference_kats_on_gpu(fa):
+    """test/testInterpolation.cc:73-155 replayed through the HIP path."""
+    g = lambda m, f, x, y, ix, iy: fa.RegridPlan(m, [x], [y], ix, iy, 1, 1).apply_host(np.asarray(f, np.float32))[0, 0, 0]
+    assert g(oracle.NEAREST, [1., 2., 1., 2.], 0.3, 0.3, 2, 2) == 1
+    f = np.array([1., 2., 2., 1 + np.sqrt(np.float32(2.0))], dtype=np.float32)
+    assert abs(g(oracle.BILINEAR, f, 0.3, 0., 2, 2) - 1.3) < 1e-6
+    assert abs(g(oracle.BILINEAR, f, 0., 0.3, 2, 2) - 1.3) < 1e-6
+    assert not np.isnan(g(oracle.BILINEAR, f, 1, 1, 2, 2))
+    for x, y in [(1.5, 0.5), (0.5, 1.5), (0.5, -0.5), (-0.5, 0.5)]:
+        assert np.isnan(g(oracle.BILINEAR, f, x, y, 2, 2))
+    c = np.array([1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1], dtype=np.float32)
+    assert abs(g(oracle.BICUBIC, c, 1, 1.5, 4, 4) - 2.125) < 2.125e-5
+    assert abs(g(oracle.BICUBIC, c, 1.5, 1, 4, 4) - 2.0) < 2e-5
+    for x, y in [(.5, 1), (1, .5), (2.5, 1), (1, 2.5)]:
+        assert np.isnan(g(oracle.BICUBIC, c, x, y, 4, 4))
+
+
+FORWARD = list(range(oracle.FWD_SUM, oracle.FWD_UNDEF_MIN + 1))
+
+
+@pytest.mark.parametrize("method", FORWARD)
+@pytest.mark.parametrize("density", [0.3, 1.0, 9.0])
+def test_forward_methods_match_oracle(fa, method, density):
+    inX, inY, outX, outY, nz = 140, 110, 60, 50, 5
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=11, density=density)
+    f = cases.field(nz, inY, inX, seed=method, nan_frac=0.05)
+    want = oracle.forward_interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    info = plan.info()
+    assert info["mappedSourceCells"] > 0 and info["maxBucket"] >= 1
+
+
+@pytest.mark.parametrize("method", [oracle.FWD_SUM, oracle.FWD_MEAN, oracle.FWD_MAX, oracle.FWD_MIN,
+                                    oracle.FWD_UNDEF_SUM, oracle.FWD_UNDEF_MEAN, oracle.FWD_UNDEF_MAX, oracle.FWD_UNDEF_MIN])
+def test_forward_long_buckets_wave_path(fa, method):
+    """~130 source cells per target cell: the wave-per-bucket reduction, still in the reference's add order."""
+    inX, inY, outX, outY, nz = 400, 300, 36, 26, 3
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=21, density=130.0)
+    f = cases.field(nz, inY, inX, seed=90 + method, nan_frac=0.03, extremes=False)
+    want = oracle.forward_interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    assert plan.info()["maxBucket"] > 64
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 4), (101, 37, 3), (7, 5, 2), (2000, 3, 1)])
+def test_vector_rotation_matches_oracle(fa, shape):
+    ox, oy, oz = shape
+    m = cases.rotation_matrix(ox, oy, seed=ox)
+    u = cases.field(oz, oy, ox, seed=1)
+    v = cases.field(oz, oy, ox, seed=2) - 280
+    wu, wv = oracle.vector_reproject_values(m, u, v, ox, oy)
+    plan = fa.VectorPlan(m, ox, oy)
+    gu, gv = plan.reproject_values_host(u, v)
+    assert cases.same(gu, wu), cases.describe_mismatch(gu, wu)
+    assert cases.same(gv, wv), cases.describe_mismatch(gv, wv)
+    assert _rel_ok(gu, wu) and _rel_ok(gv, wv)
+    # length is preserved by the rotation (test/testInterpolation.cc:575-578)
+    ok = np.isfinite(u) & np.isfinite(v) & (np.abs(u) < 1e18) & (np.abs(v) < 1e18)
+    l0 = u[ok].astype(np.float64) ** 2 + v[ok].astype(np.float64) ** 2
+    l1 = gu[ok].astype(np.float64) ** 2 + gv[ok].astype(np.float64) ** 2
+    assert np.all(np.abs(l1 - l0) <= 1e-5 * l0 + 1e-3)
+    ang = (np.random.default_rng(3).uniform(-30, 400, (oz, oy, ox))).astype(np.float32)
+    wa = oracle.vector_reproject_direction(m, ang, ox, oy)
+    ga = plan.reproject_direction_host(ang)
+    assert cases.same(ga, wa), cases.describe_mismatch(ga, wa)
+
+
+def test_vector_rotation_90_degrees(fa):
+    """test/testInterpolation.cc:396-453: a quarter turn maps u -> -v, v -> u."""
+    n = 25
+    phi = np.full(n, np.pi / 2)
+    m = np.stack([np.cos(phi), np.sin(phi), -np.sin(phi), phi], axis=1).ravel()
+    u = np.arange(n, dtype=np.float32)
+    v = (25 - np.arange(n)).astype(np.float32)
+    gu, gv = fa.VectorPlan(m, 5, 5).reproject_values_host(u, v)
+    assert np.all(np.abs(gu + v) < 1e-4) and np.all(np.abs(gv - u) < 1e-4)
+
+
+@pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2)])
+@pytest.mark.parametrize("params", [(4.0, 1.6, 100), (0.5, 1.0, 23), (4.0, 1.9, 3), (1e-9, 1.6, 41)])
+def test_fill2d_matches_oracle(fa, shape, params):
+    nx, ny, nz = shape
+    relaxCrit, corrEff, maxLoop = params
+    f = cases.holes(nz, ny, nx, seed=nx * 31 + ny)
+    got, nch = fa.fill2d_host(f, relaxCrit, corrEff, maxLoop)
+    for z in range(nz):
+        want, wn, rc = oracle.fill2d(f[z], relaxCrit, corrEff, maxLoop)
+        assert rc == oracle.OK
+        assert nch[z] == wn
+        assert cases.same(got[z], want), "slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+
+
+@pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2)])
+@pytest.mark.parametrize("params", [(20, 2), (1, 1), (5, 2), (3, 0)])
+def test_creepfill_matches_oracle(fa, shape, params):
+    nx, ny, nz = shape
+    repeat, weight = params
+    f = cases.holes(nz, ny, nx, seed=nx * 17 + ny)
+    got, nch = fa.creepfill2d_host(f, repeat, weight)
+    gotv, nchv = fa.creepfillval2d_host(f, 271.25, repeat, weight)
+    for z in range(nz):
+        want, wn, rc = oracle.creepfill2d(f[z], repeat, weight)
+        assert rc == oracle.OK and nch[z] == wn
+        assert cases.same(got[z], want), "slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+        wantv, wnv, rc = oracle.creepfillval2d(f[z], 271.25, repeat, weight)
+        assert rc == oracle.OK and nchv[z] == wnv
+        assert cases.same(gotv[z], wantv), "slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))
+
+
+def test_fills_leave_complete_and_empty_slices_alone(fa):
+    full = cases.field(1, 20, 30, seed=1, nan_frac=0, extremes=False)
+    empty = np.full((1, 20, 30), np.nan, np.float32)
+    for f in (full, empty):
+        got, n = fa.fill2d_host(f, 4.0, 1.6, 100)
+        assert cases.same(got, f)
+        got, n = fa.creepfill2d_host(f, 20, 2)
+        assert cases.same(got, f)
+    assert fa.fill2d_host(empty, 4.0, 1.6, 100)[1] == [600]
+
+
+def test_bad2nan_nan2bad_and_points2position_device(fa):
+    import torch
+    rng = np.random.default_rng(0)
+    a = rng.normal(0, 1, 100003).astype(np.float32)
+    a[rng.choice(a.size, 500, replace=False)] = np.float32(9.96921e36)
+    a[rng.choice(a.size, 300, replace=False)] = np.nan
+    for off in (0, 1):  # 16-byte aligned and unaligned start
+        t = torch.from_numpy(a.copy()).cuda()
+        v = t[off:]
+        fa.bad2nan_device(v.data_ptr(), v.numel(), 9.96921e36, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert cases.same(v.cpu().numpy(), oracle.bad2nan(a[off:], 9.96921e36))
+        fa.nan2bad_device(v.data_ptr(), v.numel(), -32767.0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert cases.same(v.cpu().numpy(), oracle.nan2bad(oracle.bad2nan(a[off:], 9.96921e36), -32767.0))
+    # points2position: ascending, descending, circular longitude
+    for axis, typ in [(np.linspace(-5, 5, 41), oracle.PROJ_AXIS), (np.linspace(9, -3, 25), oracle.PROJ_AXIS),
+                      (np.radians(np.arange(-180, 180, 1.0)), oracle.LONGITUDE), (np.radians(np.arange(0, 360, 0.5)), oracle.LONGITUDE),
+                      (np.radians(np.linspace(80, -80, 321)), oracle.LATITUDE), (np.array([1., 2., 3., 4., 5.]), oracle.PROJ_AXIS)]:
+        p = rng.uniform(-8, 8, 5000)
+        p[::97] = axis[rng.integers(0, axis.size, p[::97].size)]  # exact hits
+        p[5], p[6], p[7] = np.nan, np.inf, -np.inf
+        t = torch.from_numpy(p.copy()).cuda()
+        fa.points2position_device(t.data_ptr(), t.numel(), axis, typ, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(t.cpu().numpy(), oracle.points2position(p, axis, typ))
+
+
+def test_device_resident_apply_matches_host_apply(fa):
+    """The *_device entry point on torch-owned HBM buffers and torch's stream == the *_host round trip."""
+    import torch
+    inX, inY, outX, outY, nz = 200, 150, 120, 90, 13
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=9)
+    f = cases.field(nz, inY, inX, seed=4)
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY)
+    d_in = torch.from_numpy(f).cuda()
+    d_out = torch.empty((nz, outY, outX), dtype=torch.float32, device="cuda")
+    plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
+    assert cases.same(d_out.cpu().numpy(), want)
+    # plan built from positions already resident in HBM
+    dpx, dpy = torch.from_numpy(px).cuda(), torch.from_numpy(py).cuda()
+    plan2 = fa.RegridPlan.from_device(oracle.BICUBIC, dpx.data_ptr(), dpy.data_ptr(), px.size, inX, inY, outX, outY,
+                                      torch.cuda.current_stream().cuda_stream)
+    plan2.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert cases.same(d_out.cpu().numpy(), oracle.interpolate_values(oracle.BICUBIC, px, py, f, inX, inY, outX, outY))
+
+
+def test_concurrent_host_applies_are_reentrant(fa):
+    """interpolateValues is called from concurrent OpenMP tasks in the reference's writers
+    (src/NetCDF_CDMWriter.cc:749-753): several threads, one plan."""
+    import threading
+    inX, inY, outX, outY = 160, 120, 140, 100
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=2)
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY)
+    fields = [cases.field(3, inY, inX, seed=s) for s in range(6)]
+    wants = [oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY) for f in fields]
+    results = [None] * len(fields)
+
+    def work(i):
+        results[i] = plan.apply_host(fields[i])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(fields))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for got, want in zip(results, wants):
+        assert cases.same(got, want)

@@ -18,7 +18,7 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libfimex_amd.so")
 HOSTLIB = os.path.join(HERE, "libfimex_amd_host.so")
 
-DEVICE_SOURCES = ["capi.hip", "regrid.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip"]
+DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip"]
 
 # -ffp-contract=off: the kernels reproduce the reference's IEEE arithmetic operation by operation
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -4,8 +4,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
-#include <mutex>
-#include <unordered_map>
 
 namespace fimex_amd {
 
@@ -17,15 +15,11 @@ void set_last_error(const std::string& msg) { g_lastError = msg; }
 
 int tuning(const char* name, int fallback)
 {
-    static std::mutex mu;
-    static std::unordered_map<std::string, int> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(name);
-    if (it != cache.end()) return it->second < 0 ? fallback : it->second;
+    // read on every call so that one process can sweep settings (bench/tuning scripts); a getenv per launch is noise
     const std::string key = std::string("FIMEX_AMD_") + name;
     const char* v = std::getenv(key.c_str());
-    const int parsed = (v && *v) ? std::atoi(v) : -1;
-    cache[name] = parsed;
+    if (!v || !*v) return fallback;
+    const int parsed = std::atoi(v);
     return parsed < 0 ? fallback : parsed;
 }
 

@@ -32,6 +32,20 @@ enum class Aggregate : int { Sum = 0, Mean = 1, Median = 2, Max = 3, Min = 4 };
 
 }  // namespace fimex_amd
 
+namespace fimex_amd {
+// LDS-staged form of a bilinear plan (staged.hip): per tile the source row segments to stream into
+// LDS, per output cell two 16-bit LDS offsets (stencil rows) and the float fractions.
+struct StagedPlan {
+    bool valid = false;
+    uint32_t tileW = 0, tileH = 0, per = 0, kmax = 0, tilesX = 0, nTiles = 0;
+    size_t stagedCells = 0;  // source cells streamed per slice (16-byte granules, all tiles)
+    DeviceArray<uint32_t> tileRows;
+    DeviceArray<uint2> tileHdr;
+    DeviceArray<uint32_t> lds;
+    DeviceArray<float> xf, yf;
+};
+}  // namespace fimex_amd
+
 struct fimex_amd_regrid_plan {
     int funcType = 0;
     int device = 0;
@@ -42,6 +56,7 @@ struct fimex_amd_regrid_plan {
     fimex_amd::DeviceArray<uint32_t> pos;
     fimex_amd::DeviceArray<float> xf, yf;
     fimex_amd::DeviceArray<double> xfd, yfd;
+    fimex_amd::StagedPlan staged;
 
     // forward plans
     fimex_amd::Aggregate aggregate = fimex_amd::Aggregate::Sum;
@@ -63,6 +78,10 @@ namespace fimex_amd {
 // regrid.hip
 void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
 void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+
+// staged.hip
+bool build_staged_bilinear(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
+void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 
 // forward.hip
 void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);

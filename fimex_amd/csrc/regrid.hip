@@ -138,6 +138,10 @@ struct ApplyArgs {
     uint32_t zPerBlock;    // slices handled by one workgroup (blockIdx.y selects the chunk)
     uint32_t nTiles;       // workgroup-sized tiles per slice
     uint32_t tilesPerXcd;  // ceil(nTiles / 8)
+    uint32_t outX, outY;   // output grid
+    uint32_t tilesX;       // tiles per output row
+    uint32_t tileWLog2;    // tile = 2^tileWLog2 x (256 >> tileWLog2) output cells, lanes row-major inside it
+    uint32_t xcdRemap;     // 1: contiguous band of tiles per XCD
 };
 
 // blockIdx.x -> tile so that each XCD (blockIdx.x % 8 under round-robin dispatch) works on a
@@ -145,10 +149,13 @@ struct ApplyArgs {
 __device__ __forceinline__ bool tile_cell(const ApplyArgs& a, uint32_t& cell)
 {
     const uint32_t b = blockIdx.x;
-    const uint32_t tile = (b % kXcds) * a.tilesPerXcd + b / kXcds;
+    const uint32_t tile = a.xcdRemap ? (b % kXcds) * a.tilesPerXcd + b / kXcds : b;
     if (tile >= a.nTiles) return false;
-    cell = tile * kBlock + threadIdx.x;
-    return cell < a.nOut;
+    const uint32_t tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const uint32_t x = (tx << a.tileWLog2) + (threadIdx.x & ((1u << a.tileWLog2) - 1));
+    const uint32_t y = ty * (kBlock >> a.tileWLog2) + (threadIdx.x >> a.tileWLog2);
+    cell = y * a.outX + x;
+    return x < a.outX && y < a.outY;
 }
 
 // Addressing: buffer instructions.  A 128-bit descriptor (4 SGPRs) is built per z chunk from
@@ -170,6 +177,10 @@ __device__ __forceinline__ float ld(rsrc_t r, uint32_t voff, uint32_t soff)
 __device__ __forceinline__ void st_stream(rsrc_t r, uint32_t voff, uint32_t soff, float v)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 2);
+}
+__device__ __forceinline__ void st_plain(rsrc_t r, uint32_t voff, uint32_t soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
 __device__ __forceinline__ void write_undefined(const ApplyArgs& a, uint32_t cell, uint32_t z0, uint32_t z1)
@@ -213,7 +224,7 @@ __device__ __forceinline__ float bilinear_point(float s00, float s01, float s10,
     return (1.f - yf) * ((1.f - xf) * s00 + xf * s01) + yf * ((1.f - xf) * s10 + xf * s11);
 }
 
-template <int ZC>
+template <int ZC, bool NT = true>
 __global__ void __launch_bounds__(kBlock) bilinear_apply(ApplyArgs a, const uint32_t* __restrict__ pos,
                                                          const float* __restrict__ xfrac, const float* __restrict__ yfrac)
 {
@@ -244,8 +255,11 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply(ApplyArgs a, const uint
                 s11[k] = ld(rs, pb1 + 4u, inBytes * k);
             }
 #pragma unroll
-            for (int k = 0; k < ZC; ++k)
-                st_stream(ro, cb, outBytes * k, bilinear_point(s00[k], s01[k], s10[k], s11[k], xf, yf));
+            for (int k = 0; k < ZC; ++k) {
+                const float r = bilinear_point(s00[k], s01[k], s10[k], s11[k], xf, yf);
+                if (NT) st_stream(ro, cb, outBytes * k, r);
+                else st_plain(ro, cb, outBytes * k, r);
+            }
             src += (size_t)ZC * a.inLayer;
             o += (size_t)ZC * a.nOut;
         }
@@ -355,7 +369,15 @@ ApplyArgs make_args(const fimex_amd_regrid_plan& plan, const float* d_in, size_t
     a.ix = (uint32_t)plan.inX;
     a.inLayer = plan.inX * plan.inY;
     a.nz = (uint32_t)nz;
-    a.nTiles = (uint32_t)ceil_div(a.nOut, kBlock);
+    a.outX = (uint32_t)plan.outX;
+    a.outY = (uint32_t)plan.outY;
+    // tile shape: 2^k x (256 >> k) output cells per workgroup
+    uint32_t k = (uint32_t)tuning("TILEW_LOG2", 6);
+    if (k > 8) k = 8;
+    a.tileWLog2 = k;
+    a.tilesX = (uint32_t)ceil_div(plan.outX, (size_t)1 << k);
+    a.nTiles = a.tilesX * (uint32_t)ceil_div(plan.outY, (size_t)(kBlock >> k));
+    a.xcdRemap = tuning("XCD", 1) ? 1 : 0;
     a.tilesPerXcd = (uint32_t)ceil_div(a.nTiles, kXcds);
     // slices per workgroup: long enough to amortise the plan read, short enough that the grid
     // still holds several waves of workgroups per CU
@@ -418,12 +440,21 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
     FA_HIP(hipStreamSynchronize(stream));
     plan.info.undefinedCells = (size_t)h.undefined;
     plan.info.borderCells = (size_t)h.border;
+    // bilinear: also the LDS-staged form (staged.hip); plans whose tiles do not fit keep the gather kernel only
+    if (plan.kind == PlanKind::Bilinear && tuning("STAGED", 1) != 0 && build_staged_bilinear(plan, d_px, d_py, stream)) {
+        const auto& s = plan.staged;
+        plan.info.planBytes = s.lds.bytes() + s.xf.bytes() + s.yf.bytes() + s.tileHdr.bytes() + (size_t)s.nTiles * 2 * 4 * 48;
+    }
 }
 
 void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
 {
     if (nz == 0) return;
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
+    if (plan.kind == PlanKind::Bilinear && plan.staged.valid && tuning("STAGED", 1) != 0) {
+        launch_staged_bilinear(plan, d_in, nz, d_out, stream);
+        return;
+    }
     dim3 grid;
     const ApplyArgs a = make_args(plan, d_in, nz, d_out, grid);
     // a chunk of ZC slices is addressed through one 32-bit buffer range: fall back to ZC = 1 for huge slices
@@ -436,9 +467,23 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
         break;
     case PlanKind::Bilinear: {
         const int zc = tuning("BILINEAR_ZC", 8);
-        if (zc >= 8 && fits(8)) bilinear_apply<8><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get());
-        else if (zc >= 4 && fits(4)) bilinear_apply<4><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get());
-        else bilinear_apply<1><<<grid, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get());
+        const bool nt = tuning("NT", 1) != 0;
+        const uint32_t* pp = plan.pos.get();
+        const float *xf = plan.xf.get(), *yf = plan.yf.get();
+        if (zc >= 16 && fits(16)) {
+            if (nt) bilinear_apply<16, true><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+            else bilinear_apply<16, false><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+        } else if (zc >= 8 && fits(8)) {
+            if (nt) bilinear_apply<8, true><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+            else bilinear_apply<8, false><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+        } else if (zc >= 4 && fits(4)) {
+            if (nt) bilinear_apply<4, true><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+            else bilinear_apply<4, false><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+        } else if (zc >= 2 && fits(2)) {
+            bilinear_apply<2, true><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+        } else {
+            bilinear_apply<1, true><<<grid, kBlock, 0, stream>>>(a, pp, xf, yf);
+        }
         break;
     }
     case PlanKind::Bicubic:

@@ -1,0 +1,463 @@
+// LDS-staged bilinear regrid for gfx950 (the bandwidth path of the headline metric).
+//
+// Same arithmetic as bilinear_apply in regrid.hip (src/interpolation.c:881-957), different data
+// movement.  A per-lane gather of the 2x2 stencil straight from global memory asks the memory system
+// for the same 128-byte lines several times (measured: 3x the ideal L2 requests, 1.6x the ideal fabric
+// reads on the 4000x3000 -> 2000x2000 rotated-pole case, profiles/r01_*), because a wave's lanes
+// stride through the source and neighbouring workgroups share lines but not their timing.  Here a
+// workgroup owns a TW x TH tile of OUTPUT cells; the SOURCE cells that tile needs form a sheared
+// band (the target grid is rotated against the source grid): per source row one contiguous x range.
+// The plan stores, per tile, that list of row segments (16-byte aligned, so the staged image is a
+// little larger than the cells actually read).  For every z slice the workgroup
+//   1. streams the segments from HBM with one 16-byte load per lane -- whole lines, each requested
+//      once per tile, fully coalesced -- into the next LDS buffer (double buffered: the loads for
+//      slice z+1 are in flight while slice z is interpolated),
+//   2. gathers the 2x2 stencils from LDS (ds_read2_b32 pairs) and writes 256 contiguous bytes of
+//      output per wave.
+// The per-output plan entry shrinks to two 16-bit LDS offsets + the two float fractions.
+#include "plan.hpp"
+
+namespace fimex_amd {
+
+namespace {
+
+__device__ __forceinline__ float undefined_f() { return __uint_as_float(0x7fc00000u); }
+
+__device__ __forceinline__ bool usable(double x, double y)
+{
+    const double lim = 1073741824.0;
+    return (fabs(x) < lim) && (fabs(y) < lim);
+}
+
+constexpr int kMaxRows = 160;      // source rows one tile may span
+
+struct TileGeom {
+    uint32_t outX, outY;
+    uint32_t tileW, tileH;     // output cells per tile (tileW * tileH = 256 * outputs per lane)
+    uint32_t tilesX, nTiles;
+    uint32_t capChunks;        // 16-byte chunks one LDS buffer holds
+};
+
+// classification of one output cell: which source cells it reads (src/interpolation.c:883-954)
+struct CellNeed {
+    bool valid;
+    int64_t xa, xb, ya, yb;    // inclusive ranges of source columns / rows
+    float xf, yf;              // fractions, sign bit = nearest neighbour in that direction
+};
+
+__device__ CellNeed classify(double x, double y, int64_t ix, int64_t iy)
+{
+    CellNeed c{};
+    c.valid = false;
+    if (!usable(x, y)) return c;
+    const double flx = floor(x), fly = floor(y);
+    const int64_t x0 = (int64_t)flx, y0 = (int64_t)fly;
+    c.xf = (float)(x - flx);
+    c.yf = (float)(y - fly);
+    const bool xlin = (0 <= x0) && (x0 + 1 < ix);
+    const bool ylin = (0 <= y0) && (y0 + 1 < iy);
+    if (xlin && ylin) {
+        c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = y0; c.yb = y0 + 1;
+    } else if (xlin) {
+        const int64_t ry = (int64_t)round(y);
+        if (0 <= ry && ry < iy) { c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = c.yb = ry; c.yf = -1.f; }
+    } else {
+        const int64_t rx = (int64_t)round(x);
+        if (0 <= rx && rx < ix) {
+            if (ylin) {
+                c.valid = true; c.xa = c.xb = rx; c.ya = y0; c.yb = y0 + 1; c.xf = -1.f;
+            } else {
+                const int64_t ry = (int64_t)round(y);
+                if (0 <= ry && ry < iy) { c.valid = true; c.xa = c.xb = rx; c.ya = c.yb = ry; c.xf = -1.f; c.yf = -1.f; }
+            }
+        }
+    }
+    return c;
+}
+
+struct BuildCounters {
+    unsigned long long undefined, border, overflow, stagedChunks;
+};
+
+// One workgroup per tile: finds the row segments the tile reads and the LDS offsets of every output.
+// tileRows[tile][2*i] = global cell offset of segment i, [2*i+1] = first chunk index of segment i (prefix sum);
+// tileHdr[tile] = {nr, totalChunks}.
+__global__ void __launch_bounds__(kBlock) build_tiles_bilinear(const double* __restrict__ px, const double* __restrict__ py,
+                                                               int64_t ix, int64_t iy, TileGeom g,
+                                                               uint32_t* __restrict__ tileRows, uint2* __restrict__ tileHdr,
+                                                               uint32_t* __restrict__ lds, float* __restrict__ xfr,
+                                                               float* __restrict__ yfr, BuildCounters* counters)
+{
+    __shared__ int shRmin, shRmax;
+    __shared__ int rowMin[kMaxRows], rowMax[kMaxRows];
+    __shared__ uint32_t rowChunk[kMaxRows + 1];
+    __shared__ int shOverflow;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const uint32_t perLane = (g.tileW * g.tileH) / kBlock;
+    if (threadIdx.x == 0) { shRmin = 0x7FFFFFFF; shRmax = -1; shOverflow = 0; }
+    __syncthreads();
+    // lane owns column lx of rows ly, ly + rowsPerPass, ... of the tile (a wave covers 64 consecutive x)
+    const uint32_t lx = threadIdx.x % g.tileW;
+    const uint32_t rowsPerPass = kBlock / g.tileW;
+    const uint32_t ly0 = threadIdx.x / g.tileW;
+    for (uint32_t k = 0; k < perLane; ++k) {
+        const uint32_t x = tx * g.tileW + lx, y = ty * g.tileH + ly0 + k * rowsPerPass;
+        if (x < g.outX && y < g.outY) {
+            const size_t cell = (size_t)y * g.outX + x;
+            const CellNeed c = classify(px[cell], py[cell], ix, iy);
+            if (c.valid) { atomicMin(&shRmin, (int)c.ya); atomicMax(&shRmax, (int)c.yb); }
+        }
+    }
+    __syncthreads();
+    const int rmin = shRmin;
+    const int nr = (shRmax >= rmin) ? shRmax - rmin + 1 : 0;
+    if (nr > kMaxRows) {
+        if (threadIdx.x == 0) { atomicAdd(&counters->overflow, 1ull); tileHdr[tile] = make_uint2(0, 0); }
+        return;
+    }
+    for (int i = threadIdx.x; i < nr; i += kBlock) { rowMin[i] = 0x7FFFFFFF; rowMax[i] = -1; }
+    __syncthreads();
+    for (uint32_t k = 0; k < perLane; ++k) {
+        const uint32_t x = tx * g.tileW + lx, y = ty * g.tileH + ly0 + k * rowsPerPass;
+        if (x < g.outX && y < g.outY) {
+            const size_t cell = (size_t)y * g.outX + x;
+            const CellNeed c = classify(px[cell], py[cell], ix, iy);
+            if (c.valid)
+                for (int64_t r = c.ya; r <= c.yb; ++r) {
+                    atomicMin(&rowMin[r - rmin], (int)c.xa);
+                    atomicMax(&rowMax[r - rmin], (int)c.xb);
+                }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < nr; ++i) {
+            rowChunk[i] = acc;
+            if (rowMax[i] >= 0) {
+                const int xs = rowMin[i] & ~3;  // 16-byte aligned start (ix % 4 == 0)
+                rowMin[i] = xs;
+                acc += (uint32_t)((rowMax[i] - xs) / 4 + 1);
+            }
+        }
+        rowChunk[nr] = acc;
+        if (acc > g.capChunks) shOverflow = 1;
+    }
+    __syncthreads();
+    if (shOverflow) {
+        if (threadIdx.x == 0) { atomicAdd(&counters->overflow, 1ull); tileHdr[tile] = make_uint2(0, 0); }
+        return;
+    }
+    uint32_t* rows = tileRows + (size_t)tile * 2 * kMaxRows;
+    for (int i = threadIdx.x; i < nr; i += kBlock) {
+        rows[2 * i] = (rowMax[i] >= 0) ? (uint32_t)((int64_t)(rmin + i) * ix + rowMin[i]) : 0u;
+        rows[2 * i + 1] = rowChunk[i];
+    }
+    if (threadIdx.x == 0) {
+        tileHdr[tile] = make_uint2((uint32_t)nr, rowChunk[nr]);
+        atomicAdd(&counters->stagedChunks, (unsigned long long)rowChunk[nr]);
+    }
+    for (uint32_t k = 0; k < perLane; ++k) {
+        const uint32_t x = tx * g.tileW + lx, y = ty * g.tileH + ly0 + k * rowsPerPass;
+        if (x < g.outX && y < g.outY) {
+            const size_t cell = (size_t)y * g.outX + x;
+            const CellNeed c = classify(px[cell], py[cell], ix, iy);
+            uint32_t packed = kInvalidPos;
+            if (c.valid) {
+                const int ia = (int)(c.ya - rmin), ib = (int)(c.yb - rmin);
+                const uint32_t la = rowChunk[ia] * 4 + (uint32_t)(c.xa - rowMin[ia]);
+                const uint32_t lb = rowChunk[ib] * 4 + (uint32_t)(c.xa - rowMin[ib]);
+                packed = la | (lb << 16);
+                if ((__float_as_uint(c.xf) | __float_as_uint(c.yf)) >> 31) atomicAdd(&counters->border, 1ull);
+            } else {
+                atomicAdd(&counters->undefined, 1ull);
+            }
+            lds[cell] = packed;
+            xfr[cell] = c.valid ? c.xf : 0.f;
+            yfr[cell] = c.valid ? c.yf : 0.f;
+        }
+    }
+}
+
+struct StagedArgs {
+    const float* in;
+    float* out;
+    const uint32_t* tileRows;
+    const uint2* tileHdr;
+    const uint32_t* lds;
+    const float* xf;
+    const float* yf;
+    TileGeom g;
+    size_t inLayer;
+    uint32_t nOut;
+    uint32_t nz, zPerBlock;
+    uint32_t tilesPerXcd, xcdRemap;
+};
+
+__device__ __forceinline__ float bilinear_point(float s00, float s01, float s10, float s11, float xf, float yf)
+{
+    return (1.f - yf) * ((1.f - xf) * s00 + xf * s01) + yf * ((1.f - xf) * s10 + xf * s11);  // interpolation.c:899-900
+}
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+
+// PER: outputs per lane; KMAX: 16-byte chunks per lane and slice (KMAX * 256 * 16 bytes = one LDS buffer);
+// DEPTH: slices whose loads are in flight in registers ahead of the one being interpolated.
+template <int PER, int KMAX, int DEPTH>
+__global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers of KMAX*256*4 floats (+ slack), then the row table
+    constexpr uint32_t kBufFloats = KMAX * kBlock * 4 + 4;
+    float* buf0 = smem;
+    float* buf1 = smem + kBufFloats;
+    uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + 2 * kBufFloats);  // [2 * nr]
+
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = a.xcdRemap ? (b % kXcds) * a.tilesPerXcd + b / kXcds : b;
+    if (tile >= a.g.nTiles) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint2 hdr = a.tileHdr[tile];
+    const uint32_t nr = hdr.x, totalChunks = hdr.y;
+
+    // ---- per-lane plan: outputs and their LDS stencil offsets
+    const uint32_t tx = tile % a.g.tilesX, ty = tile / a.g.tilesX;
+    const uint32_t lx = threadIdx.x % a.g.tileW;
+    const uint32_t rowsPerPass = kBlock / a.g.tileW;
+    const uint32_t ly0 = threadIdx.x / a.g.tileW;
+    uint32_t cellOff[PER];  // byte offset of the output cell inside a slice, ~0u = not mine
+    uint32_t lds[PER];
+    float xf[PER], yf[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t x = tx * a.g.tileW + lx, y = ty * a.g.tileH + ly0 + k * rowsPerPass;
+        if (x < a.g.outX && y < a.g.outY) {
+            const uint32_t cell = y * a.g.outX + x;
+            cellOff[k] = cell * 4u;
+            lds[k] = a.lds[cell];
+            xf[k] = a.xf[cell];
+            yf[k] = a.yf[cell];
+        } else {
+            cellOff[k] = 0xFFFFFFFFu;  // dropped by the bounds check of the output descriptor
+            lds[k] = kInvalidPos;
+            xf[k] = yf[k] = 0.f;
+        }
+    }
+    const uint32_t outBytes = a.nOut * 4u;
+
+    if (totalChunks == 0) {  // nothing of the source is needed: every output of the tile is undefined
+        for (uint32_t z = z0; z < z1; ++z) {
+            const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, outBytes);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) __builtin_amdgcn_raw_buffer_store_b32(0x7fc00000u, ro, cellOff[k], 0, 2);
+        }
+        return;
+    }
+
+    // ---- per-lane staging list: chunk c = threadIdx.x + j*256 of the tile's row segments
+    const uint32_t* rows = a.tileRows + (size_t)tile * 2 * kMaxRows;
+    for (uint32_t i = threadIdx.x; i < 2 * nr; i += kBlock) shRows[i] = rows[i];
+    __syncthreads();
+    uint32_t gOff[KMAX];  // byte offset of the chunk inside a source slice, ~0u = none (dropped by the bounds check)
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const uint32_t c = threadIdx.x + j * kBlock;
+        gOff[j] = 0xFFFFFFFFu;
+        if (c < totalChunks) {
+            uint32_t lo = 0, hi = nr - 1;  // last row whose first chunk <= c
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (shRows[2 * mid + 1] <= c) lo = mid; else hi = mid - 1;
+            }
+            gOff[j] = (shRows[2 * lo] + (c - shRows[2 * lo + 1]) * 4u) * 4u;
+        }
+    }
+
+    const uint32_t inBytes = (uint32_t)a.inLayer * 4u;
+    using u4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+    u4 stage[DEPTH][KMAX];
+
+#define FA_ISSUE(set, zz)                                                                       \
+    {                                                                                           \
+        const rsrc_t rs_ = make_rsrc(a.in + (size_t)(zz) * a.inLayer, inBytes);                 \
+        _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                        \
+            stage[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_, gOff[j], 0, 0);          \
+    }
+#define FA_COMMIT(set, dst)                                                                     \
+    {                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < KMAX; ++j) {                                      \
+            const uint32_t c_ = threadIdx.x + j * kBlock;                                       \
+            if (c_ < totalChunks) reinterpret_cast<u4*>(dst)[c_] = stage[set][j];               \
+        }                                                                                       \
+    }
+
+    // prologue: slices z0 .. z0+DEPTH-1 in flight, slice z0 committed to LDS
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (z0 + d < z1) FA_ISSUE(d, z0 + d)
+    FA_COMMIT(0, buf0)
+    __syncthreads();
+    float* cur = buf0;
+    float* nxt = buf1;
+    for (uint32_t zb = z0; zb < z1; zb += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint32_t z = zb + d;
+            if (z >= z1) break;
+            // register set d held slice z (already in LDS): refill it with slice z + DEPTH
+            if (z + DEPTH < z1) FA_ISSUE(d, z + DEPTH)
+            const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, outBytes);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                float r = undefined_f();
+                if (lds[k] != kInvalidPos) {
+                    const uint32_t la = lds[k] & 0xFFFFu, lb = lds[k] >> 16;
+                    const float s00 = cur[la], s01 = cur[la + 1], s10 = cur[lb], s11 = cur[lb + 1];
+                    const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
+                    if (!(nnx || nny)) r = bilinear_point(s00, s01, s10, s11, xf[k], yf[k]);
+                    else if (nnx && nny) r = s00;                                  // interpolation.c:939-942
+                    else if (nny) r = (1.f - xf[k]) * s00 + xf[k] * s01;           // :911
+                    else r = (1 - yf[k]) * s00 + (yf[k] * s10);                    // :931
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+            }
+            if (z + 1 < z1) FA_COMMIT((d + 1) % DEPTH, nxt)
+            __syncthreads();
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+#undef FA_ISSUE
+#undef FA_COMMIT
+}
+
+template <int PER, int KMAX, int DEPTH>
+void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
+{
+    constexpr size_t ldsBytes = 2 * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
+    static bool attrSet = false;
+    if (!attrSet) {
+        FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_apply_staged<PER, KMAX, DEPTH>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        attrSet = true;
+    }
+    bilinear_apply_staged<PER, KMAX, DEPTH><<<grid, kBlock, ldsBytes, stream>>>(a);
+}
+
+template <int PER, int KMAX>
+void launch_staged_depth(const StagedArgs& a, dim3 grid, hipStream_t stream)
+{
+    switch (tuning("STAGE_DEPTH", 3)) {
+    case 1: launch_staged<PER, KMAX, 1>(a, grid, stream); break;
+    case 2: launch_staged<PER, KMAX, 2>(a, grid, stream); break;
+    case 4: launch_staged<PER, KMAX, 4>(a, grid, stream); break;
+    default: launch_staged<PER, KMAX, 3>(a, grid, stream); break;
+    }
+}
+
+}  // namespace
+
+namespace {
+
+bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream,
+                      uint32_t tileW, uint32_t per, uint32_t kmax)
+{
+    TileGeom g{};
+    g.outX = (uint32_t)plan.outX;
+    g.outY = (uint32_t)plan.outY;
+    g.tileW = tileW;
+    g.tileH = per * kBlock / tileW;
+    g.tilesX = (uint32_t)ceil_div(plan.outX, tileW);
+    g.nTiles = g.tilesX * (uint32_t)ceil_div(plan.outY, g.tileH);
+    g.capChunks = kmax * kBlock;
+    const size_t n = plan.outX * plan.outY;
+    DeviceArray<uint32_t> tileRows((size_t)g.nTiles * 2 * kMaxRows);
+    DeviceArray<uint2> tileHdr(g.nTiles);
+    DeviceArray<uint32_t> lds(n);
+    DeviceArray<float> xf(n), yf(n);
+    DeviceArray<BuildCounters> counters(1);
+    FA_HIP(hipMemsetAsync(counters.get(), 0, sizeof(BuildCounters), stream));
+    build_tiles_bilinear<<<g.nTiles, kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, g, tileRows.get(),
+                                                          tileHdr.get(), lds.get(), xf.get(), yf.get(), counters.get());
+    FA_HIP(hipGetLastError());
+    BuildCounters h{};
+    FA_HIP(hipMemcpyAsync(&h, counters.get(), sizeof(h), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    if (h.overflow != 0) return false;  // some tile's footprint does not fit this shape
+    plan.staged.tileW = g.tileW;
+    plan.staged.tileH = g.tileH;
+    plan.staged.per = per;
+    plan.staged.kmax = kmax;
+    plan.staged.tilesX = g.tilesX;
+    plan.staged.nTiles = g.nTiles;
+    plan.staged.stagedCells = (size_t)h.stagedChunks * 4;
+    plan.staged.tileRows = std::move(tileRows);
+    plan.staged.tileHdr = std::move(tileHdr);
+    plan.staged.lds = std::move(lds);
+    plan.staged.xf = std::move(xf);
+    plan.staged.yf = std::move(yf);
+    plan.staged.valid = true;
+    return true;
+}
+
+}  // namespace
+
+// Chooses the smallest LDS budget whose tiles all fit; plans without spatial coherence (or with a source row length
+// that breaks the 16-byte alignment of row starts) keep only the gather kernel.
+bool build_staged_bilinear(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+{
+    if (plan.inX % 4 != 0) return false;
+    const uint32_t tw = (uint32_t)tuning("STAGE_TW", 64);
+    if (!(tw == 32 || tw == 64 || tw == 128 || tw == 256)) return false;
+    const int forcedPer = tuning("STAGE_PER", 0), forcedK = tuning("STAGE_K", 0);
+    const uint32_t shapes[4][2] = {{4, 4}, {4, 6}, {8, 8}, {8, 12}};  // {outputs per lane, chunks per lane}
+    for (const auto& sh : shapes) {
+        if (forcedPer && (uint32_t)forcedPer != sh[0]) continue;
+        if (forcedK && (uint32_t)forcedK != sh[1]) continue;
+        if (try_build_staged(plan, d_px, d_py, stream, tw, sh[0], sh[1])) return true;
+    }
+    return false;
+}
+
+void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    const auto& s = plan.staged;
+    StagedArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.tileRows = s.tileRows.get();
+    a.tileHdr = s.tileHdr.get();
+    a.lds = s.lds.get();
+    a.xf = s.xf.get();
+    a.yf = s.yf.get();
+    a.g.outX = (uint32_t)plan.outX;
+    a.g.outY = (uint32_t)plan.outY;
+    a.g.tileW = s.tileW;
+    a.g.tileH = s.tileH;
+    a.g.tilesX = s.tilesX;
+    a.g.nTiles = s.nTiles;
+    a.g.capChunks = s.kmax * kBlock;
+    a.inLayer = plan.inX * plan.inY;
+    a.nOut = (uint32_t)(plan.outX * plan.outY);
+    a.nz = (uint32_t)nz;
+    uint32_t zpb = (uint32_t)tuning("STAGE_ZPB", 50);
+    if (zpb < 1) zpb = 1;
+    if (zpb > nz) zpb = (uint32_t)nz;
+    a.zPerBlock = zpb;
+    a.xcdRemap = tuning("XCD", 1) ? 1 : 0;
+    a.tilesPerXcd = (uint32_t)ceil_div(s.nTiles, kXcds);
+    const size_t chunks = ceil_div(nz, (size_t)zpb);
+    FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
+    const dim3 grid(a.tilesPerXcd * kXcds, (uint32_t)chunks, 1);
+    if (s.per == 4 && s.kmax == 4) launch_staged_depth<4, 4>(a, grid, stream);
+    else if (s.per == 4 && s.kmax == 6) launch_staged_depth<4, 6>(a, grid, stream);
+    else if (s.per == 8 && s.kmax == 8) launch_staged_depth<8, 8>(a, grid, stream);
+    else launch_staged_depth<8, 12>(a, grid, stream);
+    FA_HIP(hipGetLastError());
+}
+
+}  // namespace fimex_amd

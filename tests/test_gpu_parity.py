@@ -61,6 +61,35 @@ def test_backward_ragged_z_counts(fa, method, nz):
     assert cases.same(got, want), cases.describe_mismatch(got, want)
 
 
+@pytest.mark.parametrize("shape", [(400, 300, 200, 200, 10), (1000, 700, 333, 257, 7), (128, 96, 640, 480, 3), (64, 2000, 50, 300, 5)])
+@pytest.mark.parametrize("knobs", [{"STAGED": "0"}, {"STAGED": "1"}, {"STAGED": "1", "STAGE_TW": "128", "STAGE_PER": "8", "STAGE_K": "8"},
+                                   {"STAGED": "1", "STAGE_TW": "32", "STAGE_K": "6", "STAGE_ZPB": "3"}])
+def test_bilinear_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, shape, knobs):
+    """Both bilinear kernels (per-lane gather, LDS-staged tiles) on source widths that allow staging (inX % 4 == 0):
+    shrinking (several source cells per target cell), magnifying, and strongly anisotropic geometries."""
+    inX, inY, outX, outY, nz = shape
+    for k, v in knobs.items():
+        monkeypatch.setenv("FIMEX_AMD_" + k, v)
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=inX + outX)
+    f = cases.field(nz, inY, inX, seed=3)
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
+    got = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY).apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+def test_bilinear_scattered_positions_fall_back_to_gather(fa):
+    """Positions without spatial coherence (every tile would need the whole source): the staged plan does not fit
+    its LDS budget and the plan silently keeps the gather kernel; results are the same."""
+    inX, inY, outX, outY, nz = 512, 384, 200, 100, 4
+    rng = np.random.default_rng(5)
+    px = rng.uniform(-3, inX + 2, outX * outY)
+    py = rng.uniform(-3, inY + 2, outX * outY)
+    f = cases.field(nz, inY, inX, seed=8)
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
+    got = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY).apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
 def test_backward_empty_and_query(fa):
     px, py = cases.backward_positions(10, 8, 6, 5, seed=1, special=False)
     plan = fa.RegridPlan(oracle.BILINEAR, px, py, 10, 8, 6, 5)

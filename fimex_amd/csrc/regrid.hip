@@ -451,7 +451,9 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
 {
     if (nz == 0) return;
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
-    if (plan.kind == PlanKind::Bilinear && plan.staged.valid && tuning("STAGED", 1) != 0) {
+    // the staged kernel pays a per-tile set-up (row table, chunk list) that only amortises over a few slices
+    if (plan.kind == PlanKind::Bilinear && plan.staged.valid && tuning("STAGED", 1) != 0 &&
+        nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
         launch_staged_bilinear(plan, d_in, nz, d_out, stream);
         return;
     }

@@ -193,6 +193,7 @@ struct StagedArgs {
     uint32_t nOut;
     uint32_t nz, zPerBlock;
     uint32_t tilesPerXcd, xcdRemap;
+    uint32_t ablate;  // diagnostics only (FIMEX_AMD_ABLATE): 1 = no source loads, 2 = no output stores
 };
 
 __device__ __forceinline__ float bilinear_point(float s00, float s01, float s10, float s11, float xf, float yf)
@@ -206,9 +207,24 @@ __device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
 }
 
-// PER: outputs per lane; KMAX: 16-byte chunks per lane and slice (KMAX * 256 * 16 bytes = one LDS buffer);
-// DEPTH: slices whose loads are in flight in registers ahead of the one being interpolated.
-template <int PER, int KMAX, int DEPTH>
+// One LDS-DMA wave instruction: 64 lanes x 16 bytes from per-lane buffer offsets to ldsBase + lane * 16.
+// (The builtin exists only in the device pass; the host pass of hipcc parses kernel bodies too.)
+template <int AUX>
+__device__ __forceinline__ void dma16(rsrc_t rs, float* ldsBase, uint32_t voff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, AUX);
+#else
+    (void)rs; (void)ldsBase; (void)voff;
+#endif
+}
+
+// PER: outputs per lane; KMAX: 16-byte chunks per lane and slice (KMAX * 256 * 16 bytes = one LDS buffer).
+// DMA = true: the row segments go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no
+//   VGPR round trip and no ds_write); the next slice lands in the other buffer while this one is interpolated.
+// DMA = false: register staging, DEPTH slices in flight in VGPRs ahead of the one being interpolated.
+template <int PER, int KMAX, int DEPTH, bool DMA, int LDAUX = 0, int STAUX = 2>
 __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers of KMAX*256*4 floats (+ slack), then the row table
@@ -217,8 +233,20 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     float* buf1 = smem + kBufFloats;
     uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + 2 * kBufFloats);  // [2 * nr]
 
+    // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an L2), so
+    //   xcdRemap 0: neighbouring tiles of a row land on different XCDs;
+    //   xcdRemap 1: each XCD owns one contiguous band of tile rows (neighbours share an L2, but the bands differ in work);
+    //   xcdRemap >= 2: tile rows are dealt to the XCDs in stripes of (xcdRemap - 1) rows: x-neighbours share an L2
+    //                  (their partial edge lines hit) and every XCD sees the same mix of cheap and expensive rows.
     const uint32_t b = blockIdx.x;
-    const uint32_t tile = a.xcdRemap ? (b % kXcds) * a.tilesPerXcd + b / kXcds : b;
+    uint32_t tile = b;
+    if (a.xcdRemap == 1) {
+        tile = (b % kXcds) * a.tilesPerXcd + b / kXcds;
+    } else if (a.xcdRemap >= 2) {
+        const uint32_t stripe = (a.xcdRemap - 1) * a.g.tilesX;  // tiles per stripe
+        const uint32_t idx = b / kXcds;                         // position in this XCD's sequence
+        tile = ((idx / stripe) * kXcds + b % kXcds) * stripe + idx % stripe;
+    }
     if (tile >= a.g.nTiles) return;
     const uint32_t z0 = blockIdx.y * a.zPerBlock;
     const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
@@ -230,23 +258,26 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     const uint32_t lx = threadIdx.x % a.g.tileW;
     const uint32_t rowsPerPass = kBlock / a.g.tileW;
     const uint32_t ly0 = threadIdx.x / a.g.tileW;
-    uint32_t cellOff[PER];  // byte offset of the output cell inside a slice, ~0u = not mine
-    uint32_t lds[PER];
+    uint32_t cellOff[PER];  // byte offset of the output cell inside a slice; ~0u (not mine) is dropped by the bounds check
+    uint32_t la[PER], lb[PER];  // LDS byte offsets of the two stencil rows
     float xf[PER], yf[PER];
+    bool undef[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const uint32_t x = tx * a.g.tileW + lx, y = ty * a.g.tileH + ly0 + k * rowsPerPass;
+        cellOff[k] = 0xFFFFFFFFu;
+        uint32_t packed = kInvalidPos;
+        xf[k] = yf[k] = 0.f;
         if (x < a.g.outX && y < a.g.outY) {
             const uint32_t cell = y * a.g.outX + x;
             cellOff[k] = cell * 4u;
-            lds[k] = a.lds[cell];
+            packed = a.lds[cell];
             xf[k] = a.xf[cell];
             yf[k] = a.yf[cell];
-        } else {
-            cellOff[k] = 0xFFFFFFFFu;  // dropped by the bounds check of the output descriptor
-            lds[k] = kInvalidPos;
-            xf[k] = yf[k] = 0.f;
         }
+        undef[k] = packed == kInvalidPos;
+        la[k] = undef[k] ? 0u : (packed & 0xFFFFu) * 4u;  // undefined cells read LDS offset 0 and discard it
+        lb[k] = undef[k] ? 0u : (packed >> 16) * 4u;
     }
     const uint32_t outBytes = a.nOut * 4u;
 
@@ -279,21 +310,75 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     }
 
     const uint32_t inBytes = (uint32_t)a.inLayer * 4u;
+
+// shared by both staging flavours: interpolate slice z of this tile from the LDS image `cur`
+#define FA_COMPUTE(z)                                                                                              \
+    {                                                                                                              \
+        const rsrc_t ro = make_rsrc(a.out + (size_t)(z) * a.nOut, (a.ablate & 2) ? 0u : outBytes);                \
+        const char* curb = reinterpret_cast<const char*>(cur);                                                     \
+        float s00[PER], s01[PER], s10[PER], s11[PER];                                                              \
+        _Pragma("unroll") for (int k = 0; k < PER; ++k) { /* all stencil reads first: 2 x ds_read2_b32 per output */ \
+            const float* pa = reinterpret_cast<const float*>(curb + la[k]);                                        \
+            const float* pb = reinterpret_cast<const float*>(curb + lb[k]);                                        \
+            s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];                                        \
+        }                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < PER; ++k) {                                                          \
+            const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;      \
+            /* interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911) */ \
+            const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];                                             \
+            const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];                                             \
+            const float inter = (1.f - yf[k]) * top + yf[k] * bot;                                                 \
+            const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]); /* nearest in x, linear in y (:931) */     \
+            float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);                                           \
+            r = undef[k] ? undefined_f() : r;                                                                      \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, STAUX);                   \
+        }                                                                                                          \
+    }
+
+    if constexpr (DMA) {
+        // one wave instruction moves 64 chunks = 1 KiB: LDS destination = wave-uniform base + lane * 16
+        const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
+#define FA_DMA(dst, zz)                                                                                            \
+    {                                                                                                              \
+        const rsrc_t rs_ = make_rsrc(a.in + (size_t)(zz) * a.inLayer, (a.ablate & 1) ? 0u : inBytes);             \
+        _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                                           \
+            dma16<LDAUX>(rs_, (dst) + (waveChunk + j * kBlock) * 4, gOff[j]);                                      \
+    }
+        float* cur = buf0;
+        float* nxt = buf1;
+        FA_DMA(cur, z0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (uint32_t z = z0; z < z1; ++z) {
+            const bool more = z + 1 < z1;
+            if (more) FA_DMA(nxt, z + 1)
+            FA_COMPUTE(z)
+            // the DMA was issued before this slice's PER stores: wait for it, leave the stores in flight
+            if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            float* t = cur; cur = nxt; nxt = t;
+        }
+#undef FA_DMA
+        return;
+    }
+
     using u4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
     u4 stage[DEPTH][KMAX];
 
 #define FA_ISSUE(set, zz)                                                                       \
     {                                                                                           \
-        const rsrc_t rs_ = make_rsrc(a.in + (size_t)(zz) * a.inLayer, inBytes);                 \
+        const rsrc_t rs_ = make_rsrc(a.in + (size_t)(zz) * a.inLayer, (a.ablate & 1) ? 0u : inBytes); \
         _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                        \
             stage[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_, gOff[j], 0, 0);          \
     }
 #define FA_COMMIT(set, dst)                                                                     \
     {                                                                                           \
-        _Pragma("unroll") for (int j = 0; j < KMAX; ++j) {                                      \
-            const uint32_t c_ = threadIdx.x + j * kBlock;                                       \
-            if (c_ < totalChunks) reinterpret_cast<u4*>(dst)[c_] = stage[set][j];               \
-        }                                                                                       \
+        /* chunks past the tile's last one carry zeros (bounds-checked loads) into unused LDS */ \
+        _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                        \
+            reinterpret_cast<u4*>(dst)[threadIdx.x + j * kBlock] = stage[set][j];               \
     }
 
     // prologue: slices z0 .. z0+DEPTH-1 in flight, slice z0 committed to LDS
@@ -311,21 +396,7 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
             if (z >= z1) break;
             // register set d held slice z (already in LDS): refill it with slice z + DEPTH
             if (z + DEPTH < z1) FA_ISSUE(d, z + DEPTH)
-            const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, outBytes);
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                float r = undefined_f();
-                if (lds[k] != kInvalidPos) {
-                    const uint32_t la = lds[k] & 0xFFFFu, lb = lds[k] >> 16;
-                    const float s00 = cur[la], s01 = cur[la + 1], s10 = cur[lb], s11 = cur[lb + 1];
-                    const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
-                    if (!(nnx || nny)) r = bilinear_point(s00, s01, s10, s11, xf[k], yf[k]);
-                    else if (nnx && nny) r = s00;                                  // interpolation.c:939-942
-                    else if (nny) r = (1.f - xf[k]) * s00 + xf[k] * s01;           // :911
-                    else r = (1 - yf[k]) * s00 + (yf[k] * s10);                    // :931
-                }
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
-            }
+            FA_COMPUTE(z)
             if (z + 1 < z1) FA_COMMIT((d + 1) % DEPTH, nxt)
             __syncthreads();
             float* t = cur; cur = nxt; nxt = t;
@@ -333,30 +404,36 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     }
 #undef FA_ISSUE
 #undef FA_COMMIT
+#undef FA_COMPUTE
 }
 
-template <int PER, int KMAX, int DEPTH>
+template <int PER, int KMAX, int DEPTH, bool DMA, int LDAUX = 0, int STAUX = 2>
 void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
     constexpr size_t ldsBytes = 2 * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
     static bool attrSet = false;
     if (!attrSet) {
-        FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_apply_staged<PER, KMAX, DEPTH>),
+        FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_apply_staged<PER, KMAX, DEPTH, DMA, LDAUX, STAUX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
         attrSet = true;
     }
-    bilinear_apply_staged<PER, KMAX, DEPTH><<<grid, kBlock, ldsBytes, stream>>>(a);
+    bilinear_apply_staged<PER, KMAX, DEPTH, DMA, LDAUX, STAUX><<<grid, kBlock, ldsBytes, stream>>>(a);
 }
 
 template <int PER, int KMAX>
 void launch_staged_depth(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
-    switch (tuning("STAGE_DEPTH", 3)) {
-    case 1: launch_staged<PER, KMAX, 1>(a, grid, stream); break;
-    case 2: launch_staged<PER, KMAX, 2>(a, grid, stream); break;
-    case 4: launch_staged<PER, KMAX, 4>(a, grid, stream); break;
-    default: launch_staged<PER, KMAX, 3>(a, grid, stream); break;
+    if (tuning("STAGE_DMA", 1) != 0) {
+        if (PER == 4 && KMAX == 6) {  // cache-policy experiments (sweeps only)
+            const int ld = tuning("STAGE_LDAUX", 0), st = tuning("STAGE_STAUX", 2);
+            if (ld == 2 && st == 2) { launch_staged<4, 6, 1, true, 2, 2>(a, grid, stream); return; }
+            if (ld == 0 && st == 0) { launch_staged<4, 6, 1, true, 0, 0>(a, grid, stream); return; }
+            if (ld == 2 && st == 0) { launch_staged<4, 6, 1, true, 2, 0>(a, grid, stream); return; }
+        }
+        launch_staged<PER, KMAX, 1, true>(a, grid, stream);
+        return;
     }
+    launch_staged<PER, KMAX, 1, false>(a, grid, stream);
 }
 
 }  // namespace
@@ -448,11 +525,17 @@ void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in
     if (zpb < 1) zpb = 1;
     if (zpb > nz) zpb = (uint32_t)nz;
     a.zPerBlock = zpb;
-    a.xcdRemap = tuning("XCD", 1) ? 1 : 0;
+    a.xcdRemap = (uint32_t)tuning("XCD", 0);  // measured: plain round-robin is as good as any remap here (profiles/)
+    a.ablate = (uint32_t)tuning("ABLATE", 0);
     a.tilesPerXcd = (uint32_t)ceil_div(s.nTiles, kXcds);
+    uint32_t gridX = a.tilesPerXcd * kXcds;
+    if (a.xcdRemap >= 2) {  // whole stripes per XCD
+        const uint32_t stripe = (a.xcdRemap - 1) * s.tilesX;
+        gridX = (uint32_t)ceil_div(s.nTiles, (size_t)stripe * kXcds) * stripe * kXcds;
+    }
     const size_t chunks = ceil_div(nz, (size_t)zpb);
     FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
-    const dim3 grid(a.tilesPerXcd * kXcds, (uint32_t)chunks, 1);
+    const dim3 grid(gridX, (uint32_t)chunks, 1);
     if (s.per == 4 && s.kmax == 4) launch_staged_depth<4, 4>(a, grid, stream);
     else if (s.per == 4 && s.kmax == 6) launch_staged_depth<4, 6>(a, grid, stream);
     else if (s.per == 8 && s.kmax == 8) launch_staged_depth<8, 8>(a, grid, stream);

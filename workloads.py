@@ -94,6 +94,18 @@ def touched_source_cells(px, py, inX, inY, stencil):
     return int(mask.sum())
 
 
+def reduced_domain_cells(px, py, inX, inY):
+    """Cells of the bounding box CachedInterpolation::createReducedDomain (src/CachedInterpolation.cc:159-200) would
+    crop the source to: floor(min) - 2 .. ceil(max) + 2, clamped to the grid.  Positions outside the grid (the
+    -999 that mifi_points2position writes for non-finite input) take part like in the reference."""
+    px, py = np.asarray(px), np.asarray(py)
+    x0 = int(min(max(math.floor(px.min()) - 2, 0), inX - 1))
+    x1 = int(min(max(math.ceil(px.max()) + 2, 0), inX - 1))
+    y0 = int(min(max(math.floor(py.min()) - 2, 0), inY - 1))
+    y1 = int(min(max(math.ceil(py.max()) + 2, 0), inY - 1))
+    return (x1 - x0 + 1) * (y1 - y0 + 1)
+
+
 # ------------------------------------------------------------------ C4
 class ForwardLambert:
     """0.1 deg global lon/lat source (3600x1800) -> 1500x1500 Lambert grid at 2.5 km, forward methods.

@@ -215,18 +215,19 @@ def main():
                                   "achieved_GBps": b1 / (float(np.mean(k1)) * 1e-3) / 1e9}
         if dist_on:
             # write-back: RCCL gather of every rank's finished slices to rank 0 over xGMI, outside the metric
-            gl = [torch.empty_like(d_out) for _ in range(world)] if rank == 0 else None
+            from fimex_amd import sharding
             dist.barrier()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            dist.gather(d_out, gl, dst=0)
+            full = sharding.gather_slices(d_out, world * nz, dst=0)
             torch.cuda.synchronize()
             dist.barrier()
             tg = time.perf_counter() - tg
             result["gather"] = {"seconds": tg, "bytes_per_peer": d_out.numel() * 4,
                                 "GBps_into_root": (world - 1) * d_out.numel() * 4 / tg / 1e9,
-                                "note": "dist.gather (RCCL send/recv) of all output slices to rank 0; not part of value"}
-            del gl
+                                "note": "point-to-point RCCL sends of every rank's output slices to rank 0 "
+                                        "(fimex_amd/sharding.py); not part of value"}
+            del full
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         try:

@@ -17,6 +17,7 @@ HOST = os.path.join(HERE, "host")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libfimex_amd.so")
 HOSTLIB = os.path.join(HERE, "libfimex_amd_host.so")
+HOSTCLI = os.path.join(HERE, "host_cli.so")  # an executable; the .so suffix keeps it out of git and lets it travel to the GPU box
 
 DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip"]
 
@@ -75,7 +76,7 @@ def build_host(force=False):
     """C++ host mirror of the reference classes, linked against the C ABI only."""
     if not os.path.isdir(HOST):
         return None
-    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cc"))
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cc") and f != "host_cli.cc")
     if not srcs:
         return None
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")] + [
@@ -87,6 +88,13 @@ def build_host(force=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("host library build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    cli_src = os.path.join(HOST, "host_cli.cc")
+    if os.path.exists(cli_src) and (force or _newer(HOSTCLI, [cli_src, HOSTLIB] + deps)):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-o", HOSTCLI, cli_src,
+               "-L" + HERE, "-lfimex_amd_host", "-lfimex_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host_cli build failed:\n%s\n%s" % (r.stdout, r.stderr))
     return HOSTLIB
 
 

@@ -32,6 +32,14 @@ class PlanInfo(ctypes.Structure):
                 ("maxBucket", ctypes.c_size_t), ("mappedSourceCells", ctypes.c_size_t)]
 
 
+class Process2d(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("relaxCrit", ctypes.c_float), ("corrEff", ctypes.c_float),
+                ("maxLoop", ctypes.c_size_t), ("repeat", ctypes.c_ushort), ("setWeight", ctypes.c_char),
+                ("defaultVal", ctypes.c_float)]
+
+
+PROCESS_FILL2D, PROCESS_CREEPFILL2D, PROCESS_CREEPFILLVAL2D = 1, 2, 3
+
 _F = ctypes.POINTER(ctypes.c_float)
 _D = ctypes.POINTER(ctypes.c_double)
 _Z = ctypes.c_size_t
@@ -50,6 +58,8 @@ SYMBOLS = {
     "fimex_amd_regrid_plan_info": (ctypes.c_int, [_V, ctypes.POINTER(PlanInfo)]),
     "fimex_amd_regrid_apply_host": (ctypes.c_int, [_V, _F, _Z, _F, _Z, _ZP]),
     "fimex_amd_regrid_apply_device": (ctypes.c_int, [_V, _V, _Z, _V, _V]),
+    "fimex_amd_regrid_slice_host": (ctypes.c_int, [_V, _F, _Z, ctypes.c_float, ctypes.POINTER(Process2d), _Z, _F, ctypes.c_float,
+                                                   _V, ctypes.c_int, ctypes.POINTER(Process2d), _Z, _F, _Z, _ZP]),
     "fimex_amd_vector_plan_create": (ctypes.c_int, [_D, _Z, _Z, ctypes.POINTER(_V)]),
     "fimex_amd_vector_plan_destroy": (ctypes.c_int, [_V]),
     "fimex_amd_vector_reproject_values_host": (ctypes.c_int, [_V, _F, _F, _Z]),
@@ -65,6 +75,7 @@ SYMBOLS = {
     "fimex_amd_bad2nan_device": (ctypes.c_int, [_V, _Z, ctypes.c_float, _V]),
     "fimex_amd_nan2bad_device": (ctypes.c_int, [_V, _Z, ctypes.c_float, _V]),
     "fimex_amd_points2position_device": (ctypes.c_int, [_V, _Z, _D, ctypes.c_int, ctypes.c_int, _V]),
+    "fimex_amd_points2position_host": (ctypes.c_int, [_D, _Z, _D, ctypes.c_int, ctypes.c_int]),
 }
 
 _lib = None
@@ -202,6 +213,34 @@ class VectorPlan:
         _check(load().fimex_amd_vector_reproject_direction_device(self._h, d_angles, oz, stream))
 
 
+def fill2d_process(relaxCrit, corrEff, maxLoop):
+    return Process2d(PROCESS_FILL2D, relaxCrit, corrEff, maxLoop, 0, b"\0", 0.0)
+
+
+def creepfill2d_process(repeat, setWeight):
+    return Process2d(PROCESS_CREEPFILL2D, 0.0, 0.0, 0, repeat, bytes([setWeight & 0xFF]), 0.0)
+
+
+def creepfillval2d_process(repeat, setWeight, defaultVal):
+    return Process2d(PROCESS_CREEPFILLVAL2D, 0.0, 0.0, 0, repeat, bytes([setWeight & 0xFF]), defaultVal)
+
+
+def regrid_slice_host(plan, inData, badValue=float("nan"), pre=(), post=(), counterpart=None,
+                      badValueCounterpart=float("nan"), vec=None, isXComponent=True):
+    """The whole CDMInterpolator::getDataSlice body on the GPU (fimex_amd_regrid_slice_host)."""
+    a = _f32(inData).ravel()
+    c = _f32(counterpart).ravel() if counterpart is not None else None
+    pre_a = (Process2d * len(pre))(*pre) if pre else None
+    post_a = (Process2d * len(post))(*post) if post else None
+    n = _Z(0)
+    args = (plan._h, _fp(a), a.size, badValue, pre_a, len(pre), _fp(c) if c is not None else None, badValueCounterpart,
+            vec._h if vec is not None else None, 1 if isXComponent else 0, post_a, len(post))
+    _check(load().fimex_amd_regrid_slice_host(*args, None, 0, ctypes.byref(n)))
+    out = np.empty(n.value, dtype=np.float32)
+    _check(load().fimex_amd_regrid_slice_host(*args, _fp(out), out.size, ctypes.byref(n)))
+    return out.reshape(-1, plan.outY, plan.outX)
+
+
 def _slices(field):
     a = _f32(field).copy()
     if a.ndim == 2:
@@ -250,6 +289,14 @@ def bad2nan_device(d_data, n, bad, stream=0):
 
 def nan2bad_device(d_data, n, bad, stream=0):
     _check(load().fimex_amd_nan2bad_device(d_data, n, bad, stream))
+
+
+def points2position_host(points, axis, axis_type=PROJ_AXIS):
+    p = _f64(points).copy()
+    ax = _f64(axis).ravel()
+    flat = p.reshape(-1)
+    _check(load().fimex_amd_points2position_host(_dp(flat), flat.size, _dp(ax), ax.size, axis_type))
+    return p
 
 
 def points2position_device(d_points, n, axis, axis_type=PROJ_AXIS, stream=0):

@@ -422,4 +422,76 @@ int fimex_amd_points2position_device(double* d_points, size_t n, const double* a
     });
 }
 
+int fimex_amd_regrid_slice_host(const fimex_amd_regrid_plan* plan, const float* inData, size_t size, float badValue,
+                                const fimex_amd_process2d* pre, size_t nPre, const float* counterpart,
+                                float badValueCounterpart, const fimex_amd_vector_plan* vec, int isXComponent,
+                                const fimex_amd_process2d* post, size_t nPost, float* outData, size_t outCapacity,
+                                size_t* newSize)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr && newSize != nullptr, "NULL argument");
+        FA_REQUIRE((nPre == 0 || pre != nullptr) && (nPost == 0 || post != nullptr), "NULL process list");
+        const size_t inLayer = plan->inX * plan->inY, outLayer = plan->outX * plan->outY;
+        const size_t nz = size / inLayer;
+        *newSize = outLayer * nz;
+        if (outData == nullptr) return;
+        FA_REQUIRE(outCapacity >= *newSize, "output buffer too small");
+        if (nz == 0) return;
+        FA_REQUIRE(inData != nullptr, "inData is NULL");
+        const bool vector = counterpart != nullptr && vec != nullptr;
+        if (vector) FA_REQUIRE(vec->device == plan->device && vec->ox == plan->outX && vec->oy == plan->outY,
+                               "vector reprojection does not match the regrid plan");
+        ScopedDevice dev(plan->device);
+        ScopedStream stream;
+        hipStream_t st = stream.get();
+        auto run = [&](const fimex_amd_process2d* list, size_t n, float* d, size_t nx, size_t ny) {
+            for (size_t i = 0; i < n; ++i) {
+                const fimex_amd_process2d& p = list[i];
+                switch (p.kind) {
+                case FIMEX_AMD_PROCESS_FILL2D: run_fill2d(nx, ny, nz, d, p.relaxCrit, p.corrEff, p.maxLoop, nullptr, st); break;
+                case FIMEX_AMD_PROCESS_CREEPFILL2D: run_creepfill(nx, ny, nz, d, false, 0.f, p.repeat, p.setWeight, nullptr, st); break;
+                case FIMEX_AMD_PROCESS_CREEPFILLVAL2D: run_creepfill(nx, ny, nz, d, true, p.defaultVal, p.repeat, p.setWeight, nullptr, st); break;
+                default: throw Error("unknown 2-D process kind " + std::to_string(p.kind));
+                }
+            }
+        };
+        // one component: upload, fill value -> NaN, pre-processes, regrid
+        auto regrid = [&](const float* h_in, float bad, DeviceArray<float>& d_out) {
+            DeviceArray<float> d_in(nz * inLayer);
+            FA_HIP(hipMemcpyAsync(d_in.get(), h_in, d_in.bytes(), hipMemcpyHostToDevice, st));
+            launch_bad2nan(d_in.get(), d_in.size(), bad, st);
+            run(pre, nPre, d_in.get(), plan->inX, plan->inY);
+            d_out.allocate(nz * outLayer);
+            apply_device(*plan, d_in.get(), nz, d_out.get(), st);
+            FA_HIP(hipStreamSynchronize(st));  // d_in is released on return
+        };
+        DeviceArray<float> d_main, d_other;
+        regrid(inData, badValue, d_main);
+        if (vector) {
+            regrid(counterpart, badValueCounterpart, d_other);
+            if (isXComponent) launch_vector_values(*vec, d_main.get(), d_other.get(), nz, st);
+            else launch_vector_values(*vec, d_other.get(), d_main.get(), nz, st);
+        }
+        run(post, nPost, d_main.get(), plan->outX, plan->outY);
+        launch_nan2bad(d_main.get(), d_main.size(), badValue, st);
+        FA_HIP(hipMemcpyAsync(outData, d_main.get(), d_main.bytes(), hipMemcpyDeviceToHost, st));
+        stream.sync();
+    });
+}
+
+int fimex_amd_points2position_host(double* points, size_t n, const double* axis, int num, int axis_type)
+{
+    return c_guard([&] {
+        if (n == 0) return;
+        FA_REQUIRE(points != nullptr && axis != nullptr, "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(n);
+        FA_HIP(hipMemcpyAsync(d.get(), points, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        launch_points2position(d.get(), n, axis, num, axis_type, stream.get());
+        FA_HIP(hipMemcpyAsync(points, d.get(), n * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
 }  // extern "C"

@@ -1,0 +1,85 @@
+// C++ host mirror of the part of MetNoFimex::CDMInterpolator that is on the regridding hot path
+// (include/fimex/CDMInterpolator.h:140-292, src/CDMInterpolator.cc:115-287, 1242-1503): changeProjection builds
+// the cached plans, getDataSlice runs the per-slice sequence.  The upstream CDMReader is reduced to what this
+// path needs of it (GridReader); the CDM header rewrite (changeCDM) is out of scope.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "CachedInterpolation.h"
+#include "Projection.h"
+
+namespace FimexAmd {
+
+// what getDataSlice needs to know about a variable (CDMVariable / CDM::getFillValue in the reference)
+struct VariableInfo {
+    std::string name;
+    size_t levels = 1;              // z slices per unlimited-dimension step
+    double fillValue = 0;           // used when hasFillValue
+    bool hasFillValue = false;
+    bool spatialVector = false;     // CDMVariable::isSpatialVector
+    std::string counterpart;        // CDMVariable::getSpatialVectorCounterpart
+    std::string direction;          // CDMVariable::getSpatialVectorDirection, contains "x" or "y"
+};
+
+// the upstream reader as seen by this path: one horizontal grid with a projection, float slices
+class GridReader {
+public:
+    virtual ~GridReader() {}
+    virtual std::string projString() const = 0;           // proj4 string of the grid
+    virtual std::vector<double> xAxis() const = 0;         // metres, or degrees for geographic / rotated grids
+    virtual std::vector<double> yAxis() const = 0;
+    virtual std::string xDimName() const { return "x"; }
+    virtual std::string yDimName() const { return "y"; }
+    virtual bool hasVariable(const std::string& name) const = 0;
+    virtual VariableInfo variable(const std::string& name) const = 0;
+    // [levels][ny][nx] floats of one step, cropped to columns [x0, x0+nx) and rows [y0, y0+ny)
+    // (CachedInterpolationInterface::getInputDataSlice with a reduced domain, src/CachedInterpolation.cc:44-65)
+    virtual shared_array<float> getDataSlice(const std::string& varName, size_t unLimDimPos, size_t x0, size_t nx, size_t y0,
+                                             size_t ny, size_t& size) = 0;
+    // forward interpolation: longitude / latitude in degrees of every source cell, [ny][nx]; false when unavailable
+    virtual bool lonLat(std::vector<double>& lon, std::vector<double>& lat) const { (void)lon; (void)lat; return false; }
+};
+
+class CDMInterpolator {
+public:
+    explicit CDMInterpolator(std::shared_ptr<GridReader> dataReader);
+
+    // include/fimex/CDMInterpolator.h:184-193 -- method: MIFI_INTERPOL_*; axes in metres or degrees, units matching
+    // ".*degree.*" mean degrees (src/CDMInterpolator.cc:1443-1451)
+    void changeProjection(int method, const std::string& proj_input, const std::vector<double>& out_x_axis,
+                          const std::vector<double>& out_y_axis, const std::string& out_x_axis_unit,
+                          const std::string& out_y_axis_unit);
+
+    // src/CDMInterpolator.cc:235-287; returns [levels][outY][outX] floats with the variable's fill value restored
+    shared_array<float> getDataSlice(const std::string& varName, size_t unLimDimPos, size_t& size);
+
+    void addPreprocess(std::shared_ptr<InterpolatorProcess2d> process) { preprocesses_.push_back(process); }
+    void addPostprocess(std::shared_ptr<InterpolatorProcess2d> process) { postprocesses_.push_back(process); }
+
+    std::shared_ptr<CachedInterpolationInterface> cachedInterpolation() const { return cachedInterpolation_; }
+    std::shared_ptr<CachedVectorReprojection> cachedVectorReprojection() const { return cachedVectorReprojection_; }
+    // the positions the plan was built from (for tests): per output cell (backward) or per input cell (forward)
+    const std::vector<double>& pointsOnXAxis() const { return pointsOnXAxis_; }
+    const std::vector<double>& pointsOnYAxis() const { return pointsOnYAxis_; }
+    const std::vector<double>& rotationMatrix() const { return matrix_; }
+
+private:
+    std::shared_ptr<GridReader> dataReader_;
+    std::vector<std::shared_ptr<InterpolatorProcess2d>> preprocesses_, postprocesses_;
+    std::shared_ptr<CachedInterpolationInterface> cachedInterpolation_;
+    std::shared_ptr<CachedVectorReprojection> cachedVectorReprojection_;
+    std::vector<double> pointsOnXAxis_, pointsOnYAxis_, matrix_;
+
+    void changeProjectionByProjectionParameters(int method, const std::string& proj_input, std::vector<double> outXAxis,
+                                                std::vector<double> outYAxis, bool xDegree, bool yDegree);
+    void changeProjectionByForwardInterpolation(int method, const std::string& proj_input, std::vector<double> outXAxis,
+                                                std::vector<double> outYAxis, bool xDegree, bool yDegree);
+    shared_array<float> readInput(const std::string& varName, size_t unLimDimPos, size_t& size) const;
+    void processArray(const std::vector<std::shared_ptr<InterpolatorProcess2d>>& processes, float* array, size_t size, size_t nx, size_t ny) const;
+};
+
+}  // namespace FimexAmd

@@ -1,0 +1,174 @@
+// Test driver for the C++ host mirror (tests/test_host_cdminterpolator.py): reads a grid description and float
+// slices from simple binary files, runs CDMInterpolator::changeProjection + getDataSlice, writes the results.
+//
+// usage: host_cli <spec.txt> <out_dir>
+// spec.txt (one item per line):
+//   proj <proj4 string of the source grid>
+//   xaxis <file of doubles>      yaxis <file of doubles>
+//   var <name> <levels> <file of floats [steps][levels][ny][nx]> <fill|nan> [vector <counterpart> <x|y>]
+//   method <name>                 outproj <proj4>
+//   outx <file of doubles> <unit> outy <file of doubles> <unit>
+//   pre|post fill2d <relaxCrit> <corrEff> <maxLoop> | creepfill2d <repeat> <weight> | creepfillval2d <repeat> <weight> <default>
+//   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32)
+// Also writes <out_dir>/points_x.f64, points_y.f64 (plan positions) and matrix.f64 (rotation matrix, if any).
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+
+#include "CDMInterpolator.h"
+
+using namespace FimexAmd;
+
+template <typename T>
+static std::vector<T> readAll(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw CDMException("cannot read " + path);
+    const size_t bytes = (size_t)f.tellg();
+    std::vector<T> v(bytes / sizeof(T));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), bytes);
+    return v;
+}
+
+template <typename T>
+static void writeAll(const std::string& path, const T* p, size_t n)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(p), n * sizeof(T));
+}
+
+class FileGridReader : public GridReader {
+public:
+    std::string proj;
+    std::vector<double> x, y;
+    std::map<std::string, VariableInfo> vars;
+    std::map<std::string, std::vector<float>> data;
+    std::string projString() const override { return proj; }
+    std::vector<double> xAxis() const override { return x; }
+    std::vector<double> yAxis() const override { return y; }
+    bool hasVariable(const std::string& n) const override { return vars.count(n) != 0; }
+    VariableInfo variable(const std::string& n) const override { return vars.at(n); }
+    shared_array<float> getDataSlice(const std::string& n, size_t step, size_t x0, size_t nx, size_t y0, size_t ny, size_t& size) override
+    {
+        const VariableInfo& v = vars.at(n);
+        const std::vector<float>& d = data.at(n);
+        const size_t NX = x.size(), NY = y.size();
+        size = v.levels * nx * ny;
+        shared_array<float> out(new float[size ? size : 1]);
+        for (size_t l = 0; l < v.levels; ++l)
+            for (size_t j = 0; j < ny; ++j)
+                for (size_t i = 0; i < nx; ++i)
+                    out[(l * ny + j) * nx + i] = d[((step * v.levels + l) * NY + y0 + j) * NX + x0 + i];
+        return out;
+    }
+};
+
+// host-only modes (no GPU): the projection code on its own
+//   host_cli --project <src proj4> <dst proj4> <x.f64> <y.f64> <out_dir>     -> out_dir/px.f64, py.f64
+//   host_cli --matrix <in proj4> <out proj4> <outx.f64> <outy.f64> <out_dir>  -> out_dir/matrix.f64 (axes in projection units)
+//   host_cli --method <name>                                                  -> prints the method code
+static int hostOnly(int argc, char** argv)
+{
+    const std::string mode = argv[1];
+    if (mode == "--method" && argc == 3) {
+        std::cout << mifi_string_to_interpolation_method(argv[2]) << std::endl;
+        return 0;
+    }
+    if (argc != 7) return 2;
+    const Projection a(argv[2]), b(argv[3]);
+    std::vector<double> x = readAll<double>(argv[4]), y = readAll<double>(argv[5]);
+    const std::string outDir = argv[6];
+    if (mode == "--project") {
+        transform(a, b, x.data(), y.data(), x.size());
+        writeAll(outDir + "/px.f64", x.data(), x.size());
+        writeAll(outDir + "/py.f64", y.data(), y.size());
+        return 0;
+    }
+    if (mode == "--matrix") {
+        std::vector<double> m;
+        vectorReprojectMatrix(a, b, x, y, m);
+        writeAll(outDir + "/matrix.f64", m.data(), m.size());
+        return 0;
+    }
+    return 2;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 2 && std::string(argv[1]).rfind("--", 0) == 0) {
+        try {
+            const int rc = hostOnly(argc, argv);
+            if (rc == 2) std::cerr << "bad arguments\n";
+            return rc;
+        } catch (const std::exception& e) {
+            std::cerr << e.what() << std::endl;
+            return 1;
+        }
+    }
+    if (argc != 3) { std::cerr << "usage: host_cli <spec.txt> <out_dir>\n"; return 2; }
+    try {
+        auto reader = std::make_shared<FileGridReader>();
+        std::ifstream spec(argv[1]);
+        const std::string outDir = argv[2];
+        std::string line, method, outproj, outxUnit, outyUnit;
+        std::vector<double> outx, outy;
+        std::vector<std::pair<std::string, size_t>> gets;
+        std::vector<std::pair<bool, std::shared_ptr<InterpolatorProcess2d>>> procs;
+        while (std::getline(spec, line)) {
+            std::istringstream in(line);
+            std::string key;
+            if (!(in >> key)) continue;
+            if (key == "proj") { std::getline(in, reader->proj); }
+            else if (key == "outproj") { std::getline(in, outproj); }
+            else if (key == "xaxis") { std::string f; in >> f; reader->x = readAll<double>(f); }
+            else if (key == "yaxis") { std::string f; in >> f; reader->y = readAll<double>(f); }
+            else if (key == "outx") { std::string f; in >> f >> outxUnit; outx = readAll<double>(f); }
+            else if (key == "outy") { std::string f; in >> f >> outyUnit; outy = readAll<double>(f); }
+            else if (key == "method") { in >> method; }
+            else if (key == "var") {
+                VariableInfo v;
+                std::string file, fill, kw;
+                in >> v.name >> v.levels >> file >> fill;
+                if (fill != "nan") { v.hasFillValue = true; v.fillValue = std::stod(fill); }
+                if (in >> kw && kw == "vector") { v.spatialVector = true; in >> v.counterpart >> v.direction; }
+                reader->vars[v.name] = v;
+                reader->data[v.name] = readAll<float>(file);
+            } else if (key == "pre" || key == "post") {
+                std::string kind;
+                in >> kind;
+                std::shared_ptr<InterpolatorProcess2d> p;
+                if (kind == "fill2d") { float a, b; size_t n; in >> a >> b >> n; p = std::make_shared<InterpolatorFill2d>(a, b, n); }
+                else if (kind == "creepfill2d") { int r, w; in >> r >> w; p = std::make_shared<InterpolatorCreepFill2d>((unsigned short)r, (char)w); }
+                else if (kind == "creepfillval2d") { int r, w; float d; in >> r >> w >> d; p = std::make_shared<InterpolatorCreepFillVal2d>((unsigned short)r, (char)w, d); }
+                else throw CDMException("unknown process " + kind);
+                procs.push_back({key == "pre", p});
+            } else if (key == "get") { std::string v; size_t s; in >> v >> s; gets.push_back({v, s}); }
+        }
+        CDMInterpolator interp(reader);
+        for (auto& p : procs) { if (p.first) interp.addPreprocess(p.second); else interp.addPostprocess(p.second); }
+        const int m = mifi_string_to_interpolation_method(method.c_str());
+        if (m == MIFI_INTERPOL_UNKNOWN) throw CDMException("unknown method " + method);
+        interp.changeProjection(m, outproj, outx, outy, outxUnit, outyUnit);
+        writeAll(outDir + "/points_x.f64", interp.pointsOnXAxis().data(), interp.pointsOnXAxis().size());
+        writeAll(outDir + "/points_y.f64", interp.pointsOnYAxis().data(), interp.pointsOnYAxis().size());
+        writeAll(outDir + "/matrix.f64", interp.rotationMatrix().data(), interp.rotationMatrix().size());
+        auto ci = interp.cachedInterpolation();
+        std::cout << "inX " << ci->getInX() << " inY " << ci->getInY() << " outX " << ci->getOutX() << " outY " << ci->getOutY();
+        if (auto rd = ci->reducedDomain()) std::cout << " reduced xMin " << rd->xMin << " yMin " << rd->yMin;
+        std::cout << std::endl;
+        for (auto& g : gets) {
+            size_t size = 0;
+            shared_array<float> out = interp.getDataSlice(g.first, g.second, size);
+            writeAll(outDir + "/" + g.first + "_" + std::to_string(g.second) + ".f32", out.get(), size);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -175,6 +175,41 @@ int fimex_amd_creepfillval2d_host(size_t nx, size_t ny, size_t nz, float* field,
 int fimex_amd_creepfillval2d_device(size_t nx, size_t ny, size_t nz, float* d_field, float defaultVal,
                                     unsigned short repeat, char setWeight, size_t* nChanged, void* stream);
 
+/* ------------------------------------------- the whole per-slice sequence */
+/** One registered 2-D process: the parameters of InterpolatorFill2d / InterpolatorCreepFill2d /
+ *  InterpolatorCreepFillVal2d (include/fimex/CDMInterpolator.h:55-88). */
+#define FIMEX_AMD_PROCESS_FILL2D 1
+#define FIMEX_AMD_PROCESS_CREEPFILL2D 2
+#define FIMEX_AMD_PROCESS_CREEPFILLVAL2D 3
+typedef struct fimex_amd_process2d {
+    int kind;               /* FIMEX_AMD_PROCESS_* */
+    float relaxCrit;        /* fill2d */
+    float corrEff;          /* fill2d */
+    size_t maxLoop;         /* fill2d */
+    unsigned short repeat;  /* creepfill */
+    char setWeight;         /* creepfill */
+    float defaultVal;       /* creepfillval2d */
+} fimex_amd_process2d;
+
+/**
+ * Replaces the body of CDMInterpolator::getDataSlice between reading the input and converting the output
+ * (src/CDMInterpolator.cc:255-285) with the data staying in HBM between the steps:
+ *   fill value -> NaN (:115-119), pre-processes per z slice (:256, :136-159), interpolateValues (:259),
+ *   for an x/y vector component: the same on the counterpart, then reprojectValues (:261-283),
+ *   post-processes (:284), NaN -> fill value (:285, without the type conversion, which stays with Data).
+ * inData / counterpart: host [size/(inX*inY)][inY][inX]; badValue*: the variables' fill values (NaN = none).
+ * counterpart == NULL or vec == NULL: scalar variable.  isXComponent != 0: inData is the x component (u) and
+ * counterpart the y component (v); otherwise the other way round; outData receives the requested component.
+ * pre / post: the registered processes in order (may be NULL when the count is 0).
+ * outData == NULL queries *newSize only.
+ */
+int fimex_amd_regrid_slice_host(const fimex_amd_regrid_plan* plan, const float* inData, size_t size, float badValue,
+                                const fimex_amd_process2d* pre, size_t nPre,
+                                const float* counterpart, float badValueCounterpart,
+                                const fimex_amd_vector_plan* vec, int isXComponent,
+                                const fimex_amd_process2d* post, size_t nPost,
+                                float* outData, size_t outCapacity, size_t* newSize);
+
 /* ------------------------------------------------- edges of the path (a13) */
 /** mifi_bad2nanf / mifi_nanf2bad, src/interpolation.c:1775-1793, on n device floats in place. */
 int fimex_amd_bad2nan_device(float* d_data, size_t n, float badVal, void* stream);
@@ -184,6 +219,8 @@ int fimex_amd_nan2bad_device(float* d_data, size_t n, float badVal, void* stream
 /** mifi_points2position, include/fimex/interpolation.h:415, src/interpolation.c:148-217:
  *  n device doubles (radians or metres) -> fractional axis indices, in place. axis: host, num entries. */
 int fimex_amd_points2position_device(double* d_points, size_t n, const double* axis, int num, int axis_type, void* stream);
+/** Same on n host doubles (copied to the GPU and back). */
+int fimex_amd_points2position_host(double* points, size_t n, const double* axis, int num, int axis_type);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,159 @@
+"""The C++ host mirror of CDMInterpolator (fimex_amd/host/, over the C ABI) end to end on the GPU:
+BASELINE configs[0] -- coordTest.nc reprojected to a 200x200 lat/lon grid -- and a forward-interpolation case.
+
+Parity is checked in two layers: the plan positions / rotation matrix the C++ host computes against the oracle's
+restatement of the same chain (projection code differs in libm rounding: tolerance), and the regridded data against
+the oracle fed with exactly those positions (same arithmetic: bit-exact)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from oracle import proj_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "fimex_amd", "host_cli.so")
+GEO = "+proj=latlong +R=6371000"
+
+
+def _run(tmp, spec_lines):
+    spec = tmp / "spec.txt"
+    spec.write_text("\n".join(spec_lines) + "\n")
+    out = tmp / "out"
+    out.mkdir(exist_ok=True)
+    r = subprocess.run([CLI, str(spec), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out, r.stdout
+
+
+@pytest.fixture(scope="module")
+def coordtest(golden_dir):
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "coordTest.nc"), "r", mmap=False) as f:
+        v = f.variables
+        d = dict(x=v["x"].data.astype(np.float64), y=v["y"].data.astype(np.float64), proj=v["projection_1"].proj4.decode())
+        for n in ("air_temperature", "x_wind_10m", "y_wind_10m", "precipitation_amount", "cloud_area_fraction_in_atmosphere_layer"):
+            a = v[n].data.astype(np.float32)  # Data::asFloat(): raw stored values as float
+            d[n] = a.reshape(a.shape[0], -1, 11, 11)
+            d[n + "_fill"] = getattr(v[n], "_FillValue", None)
+    return d
+
+
+def _spec_common(tmp, ct, method, extra=()):
+    ct["x"].tofile(tmp / "x.f64")
+    ct["y"].tofile(tmp / "y.f64")
+    lon = np.linspace(-15.2, -9.7, 200)
+    lat = np.linspace(28.3, 33.0, 200)
+    lon.tofile(tmp / "ox.f64")
+    lat.tofile(tmp / "oy.f64")
+    lines = ["proj " + ct["proj"], "xaxis %s" % (tmp / "x.f64"), "yaxis %s" % (tmp / "y.f64"), "method " + method,
+             "outproj " + GEO, "outx %s degrees_east" % (tmp / "ox.f64"), "outy %s degrees_north" % (tmp / "oy.f64")]
+    for n, vec in (("air_temperature", ""), ("x_wind_10m", " vector y_wind_10m x"), ("y_wind_10m", " vector x_wind_10m y"),
+                   ("cloud_area_fraction_in_atmosphere_layer", "")):
+        ct[n].tofile(tmp / (n + ".f32"))
+        fill = ct[n + "_fill"]
+        lines.append("var %s %d %s %s%s" % (n, ct[n].shape[1], tmp / (n + ".f32"), "nan" if fill is None else repr(float(fill)), vec))
+    return lines + list(extra), lon, lat
+
+
+def _oracle_positions(ct, lon, lat):
+    px, py = po.project_axes(GEO, ct["proj"], np.radians(lon), np.radians(lat))
+    return oracle.points2position(px, ct["x"]), oracle.points2position(py, ct["y"])
+
+
+@pytest.mark.parametrize("method,code", [("bilinear", oracle.BILINEAR), ("nearestneighbor", oracle.NEAREST), ("bicubic", oracle.BICUBIC)])
+def test_coordtest_to_latlon_200x200(tmp_path, coordtest, method, code):
+    ct = coordtest
+    gets = ["get air_temperature 0", "get air_temperature 3", "get cloud_area_fraction_in_atmosphere_layer 1",
+            "get x_wind_10m 2", "get y_wind_10m 2"]
+    lines, lon, lat = _spec_common(tmp_path, ct, method, gets)
+    out, stdout = _run(tmp_path, lines)
+    assert "outX 200 outY 200" in stdout and "reduced" in stdout
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    wx, wy = _oracle_positions(ct, lon, lat)
+    np.testing.assert_allclose(px, wx, atol=1e-7)
+    np.testing.assert_allclose(py, wy, atol=1e-7)
+    assert (px < -0.5).any() and (px > 10.5).any()  # the target overshoots the 11x11 source
+
+    def regrid(name, step):
+        f = oracle.bad2nan(ct[name][step], ct[name + "_fill"]) if ct[name + "_fill"] is not None else ct[name][step]
+        return oracle.interpolate_values(code, px, py, f, 11, 11, 200, 200)
+
+    def back(a, name):
+        return oracle.nan2bad(a, ct[name + "_fill"]) if ct[name + "_fill"] is not None else a
+
+    for name, step in (("air_temperature", 0), ("air_temperature", 3), ("cloud_area_fraction_in_atmosphere_layer", 1)):
+        got = np.fromfile(out / ("%s_%d.f32" % (name, step)), dtype=np.float32).reshape(-1, 200, 200)
+        want = back(regrid(name, step), name)
+        assert got.shape == want.shape
+        assert cases.same(got, want), "%s: %s" % (name, cases.describe_mismatch(got, want))
+    # x/y wind pair: both components regridded, then rotated with the matrix the host built
+    m = np.fromfile(out / "matrix.f64")
+    assert m.size == 4 * 200 * 200
+    u, v = regrid("x_wind_10m", 2), regrid("y_wind_10m", 2)
+    ru, rv = oracle.vector_reproject_values(m, u, v, 200, 200)
+    gu = np.fromfile(out / "x_wind_10m_2.f32", dtype=np.float32).reshape(-1, 200, 200)
+    gv = np.fromfile(out / "y_wind_10m_2.f32", dtype=np.float32).reshape(-1, 200, 200)
+    assert cases.same(gu, back(ru, "x_wind_10m")), cases.describe_mismatch(gu, back(ru, "x_wind_10m"))
+    assert cases.same(gv, back(rv, "y_wind_10m")), cases.describe_mismatch(gv, back(rv, "y_wind_10m"))
+    # the rotation matrix itself against the oracle's restatement of mifi_get_vector_reproject_matrix
+    from test_oracle_kats import _rotation_matrix
+    wm = _rotation_matrix(ct["proj"], GEO, lon, lat, oracle.LONGITUDE, oracle.LATITUDE)
+    np.testing.assert_allclose(m.reshape(-1, 4)[:, :2], wm.reshape(-1, 4)[:, :2], atol=1e-6)
+    # wind speed survives the rotation where both components are defined (test/testInterpolation.cc:575-578)
+    ok = ~np.isnan(u) & ~np.isnan(v)
+    np.testing.assert_allclose(np.hypot(gu[ok], gv[ok]), np.hypot(u[ok], v[ok]), rtol=1e-5)
+
+
+def test_coordtest_with_pre_and_postprocess(tmp_path, coordtest):
+    """--interpolate.preprocess creepfill2d / .postprocess fill2d as in test/testInterpolation2DataFillValue.sh and
+    testInterpolatorFill.sh: fills run per z slice before and after the regrid, all on the GPU."""
+    ct = dict(coordtest)
+    t = ct["air_temperature"].copy()
+    rng = np.random.default_rng(3)
+    t.reshape(-1)[rng.choice(t.size, 60, replace=False)] = ct["air_temperature_fill"]  # punch holes
+    ct["air_temperature"] = t
+    extra = ["pre creepfill2d 5 2", "post fill2d 4.0 1.6 100", "get air_temperature 1"]
+    lines, lon, lat = _spec_common(tmp_path, ct, "bilinear", extra)
+    out, _ = _run(tmp_path, lines)
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    f = oracle.bad2nan(t[1], ct["air_temperature_fill"])
+    f = np.stack([oracle.creepfill2d(s, 5, 2)[0] for s in f])
+    r = oracle.interpolate_values(oracle.BILINEAR, px, py, f, 11, 11, 200, 200)
+    r = np.stack([oracle.fill2d(s, 4.0, 1.6, 100)[0] for s in r])
+    want = oracle.nan2bad(r, ct["air_temperature_fill"])
+    got = np.fromfile(out / "air_temperature_1.f32", dtype=np.float32).reshape(-1, 200, 200)
+    assert not np.isnan(got).any() and not (got == ct["air_temperature_fill"]).any()  # fill2d closed the outside too
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+@pytest.mark.parametrize("method,code", [("forward_mean", oracle.FWD_MEAN), ("forward_max", oracle.FWD_MAX), ("forward_median", oracle.FWD_MEDIAN)])
+def test_forward_interpolation_latlon_to_lambert(tmp_path, method, code):
+    """changeProjectionByForwardInterpolation: a 0.25-degree lat/lon source scattered onto a 40x30 Lambert grid."""
+    lon = np.arange(0, 30, 0.25)
+    lat = np.arange(55, 72, 0.25)
+    lcc = "+proj=lcc +lat_0=63 +lon_0=15 +lat_1=63 +lat_2=63 +no_defs +R=6.371e+06"
+    ox = (np.arange(40) - 19.5) * 25000.0
+    oy = (np.arange(30) - 14.5) * 25000.0
+    f = cases.field(2 * 3, lat.size, lon.size, seed=5, nan_frac=0.05, extremes=False).reshape(2, 3, lat.size, lon.size)
+    for name, a in (("x", lon), ("y", lat), ("ox", ox), ("oy", oy)):
+        a.astype(np.float64).tofile(tmp_path / (name + ".f64"))
+    f.tofile(tmp_path / "f.f32")
+    lines = ["proj " + GEO, "xaxis %s" % (tmp_path / "x.f64"), "yaxis %s" % (tmp_path / "y.f64"), "method " + method,
+             "outproj " + lcc, "outx %s m" % (tmp_path / "ox.f64"), "outy %s m" % (tmp_path / "oy.f64"),
+             "var field 3 %s nan" % (tmp_path / "f.f32"), "get field 1"]
+    out, _ = _run(tmp_path, lines)
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    assert px.size == lon.size * lat.size
+    wx, wy = po.project_axes(GEO, lcc, np.radians(lon), np.radians(lat))
+    np.testing.assert_allclose(px, oracle.points2position(wx, ox), atol=1e-6)
+    np.testing.assert_allclose(py, oracle.points2position(wy, oy), atol=1e-6)
+    want = oracle.forward_interpolate_values(code, px, py, f[1], lon.size, lat.size, 40, 30)
+    got = np.fromfile(out / "field_1.f32", dtype=np.float32).reshape(3, 30, 40)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.isfinite(got).mean() > 0.5

@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--method", default="bilinear", choices=["bilinear", "bicubic", "nearest"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-slice and gather measurements")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --one-device rehearses the N > 1 path on a single-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -129,10 +132,15 @@ def main():
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     if args.gpus != world and rank == 0:
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     fa.load()
@@ -156,7 +164,7 @@ def main():
         plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream)
 
     wall, kernel_ms = time_launches(torch, step, args.steps, args.warmup, dist_on)
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if dist_on:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall_max = float(wall_t.item())
@@ -219,7 +227,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            full = sharding.gather_slices(d_out, world * nz, dst=0)
+            # (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)
+            full = sharding.gather_slices(d_out if args.backend == "nccl" else d_out.cpu(), world * nz, dst=0)
             torch.cuda.synchronize()
             dist.barrier()
             tg = time.perf_counter() - tg

@@ -1,0 +1,127 @@
+"""BASELINE.json configurations at their full sizes on the GPU (a few slices each), through the C ABI.
+
+Grids are the benchmark's own (workloads.py).  The CPU oracle is fast enough to check whole slices at these sizes
+(OpenMP over output cells), so every case is compared in full; size-independent properties ride along: both bilinear
+kernels agree, slices are independent (batching / order do not matter), a constant field stays constant, rotation
+preserves vector length, a filled field has no holes and keeps its defined cells."""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import workloads
+from oracle import proj_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    from fimex_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1
+    return capi
+
+
+@pytest.fixture(scope="module")
+def c2(fa):
+    """configs[1]/[2]: 4000x3000 lon/lat -> 2000x2000 rotated pole; positions through the product's points2position."""
+    wl = workloads.BilinearRotatedPole()
+    lon, lat = wl.target_lonlat()
+    ax, ay = wl.source_axes_rad()
+    px = fa.points2position_host(lon, ax, fa.LONGITUDE)
+    py = fa.points2position_host(lat, ay, fa.LATITUDE)
+    np.testing.assert_array_equal(px, oracle.points2position(lon, ax, oracle.LONGITUDE))
+    np.testing.assert_array_equal(py, oracle.points2position(lat, ay, oracle.LATITUDE))
+    base = wl.base_field()
+    f = np.stack([base + np.float32(0.01 * k) for k in range(5)])
+    return wl, px, py, f
+
+
+@pytest.mark.parametrize("method", [oracle.BILINEAR, oracle.NEAREST, oracle.BICUBIC])
+def test_c2_c3_full_grid_matches_oracle(fa, c2, method):
+    wl, px, py, f = c2
+    plan = fa.RegridPlan(method, px, py, wl.inX, wl.inY, wl.outX, wl.outY)
+    got = plan.apply_host(f)
+    want = oracle.interpolate_values(method, px, py, f, wl.inX, wl.inY, wl.outX, wl.outY, nthreads=16)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    info = plan.info()
+    assert info["undefinedCells"] == int(np.isnan(oracle.interpolate_values(method, px, py, np.zeros((1, wl.inY, wl.inX), np.float32),
+                                                                            wl.inX, wl.inY, wl.outX, wl.outY, nthreads=16)).sum())
+    # slices are independent: one call over 5 slices == 5 calls, in any order
+    perm = [3, 0, 4, 1, 2]
+    assert cases.same(plan.apply_host(f[perm]), got[perm])
+    assert cases.same(plan.apply_host(f[2:3]), got[2:3])
+
+
+def test_c2_both_bilinear_kernels_agree_and_constants_survive(fa, c2, monkeypatch):
+    wl, px, py, f = c2
+    monkeypatch.setenv("FIMEX_AMD_STAGED", "1")
+    staged = fa.RegridPlan(oracle.BILINEAR, px, py, wl.inX, wl.inY, wl.outX, wl.outY).apply_host(f)
+    monkeypatch.setenv("FIMEX_AMD_STAGED", "0")
+    gather = fa.RegridPlan(oracle.BILINEAR, px, py, wl.inX, wl.inY, wl.outX, wl.outY)
+    assert cases.same(gather.apply_host(f), staged)
+    const = np.full((4, wl.inY, wl.inX), 273.15, np.float32)
+    out = gather.apply_host(const)
+    ok = ~np.isnan(out)
+    assert ok.mean() > 0.85
+    np.testing.assert_allclose(out[ok], 273.15, rtol=3e-7)
+
+
+def test_c4_forward_mean_global_to_lambert(fa):
+    """configs[3]: 0.1-degree global lon/lat -> 1500x1500 Lambert, forward methods."""
+    wl = workloads.ForwardLambert()
+    x, y = wl.source_in_target_metres()
+    px = fa.points2position_host(x, wl.x_axis)
+    py = fa.points2position_host(y, wl.y_axis)
+    np.testing.assert_array_equal(px, oracle.points2position(x, wl.x_axis))
+    base = wl.base_field()
+    f = np.stack([base, base * np.float32(1.5) - np.float32(3)])
+    for method in (oracle.FWD_MEAN, oracle.FWD_SUM, oracle.FWD_MAX, oracle.FWD_MEDIAN, oracle.FWD_UNDEF_MIN):
+        plan = fa.RegridPlan(method, px, py, wl.inX, wl.inY, wl.outX, wl.outY)
+        got = plan.apply_host(f)
+        want = oracle.forward_interpolate_values(method, px, py, f, wl.inX, wl.inY, wl.outX, wl.outY)
+        assert cases.same(got, want), "%d: %s" % (method, cases.describe_mismatch(got, want))
+    info = plan.info()
+    # the source is coarser than the target: most buckets hold one cell or none
+    assert 0 < info["mappedSourceCells"] < wl.inX * wl.inY // 4 and 1 <= info["maxBucket"] <= 8
+    assert info["undefinedCells"] > wl.outX * wl.outY // 2
+
+
+def test_c5_wind_pair_rotation_and_creepfill(fa):
+    """configs[4]: u/v on a 3000x3000 polar-stereographic grid -> lat/lon bilinear, rotated, creepfill2d(20, 2)."""
+    n = 3000
+    stere = "+proj=stere +lat_0=90 +lon_0=0 +lat_ts=60 +R=6371000"
+    geo = "+proj=latlong +R=6371000"
+    sx = (np.arange(n) - n / 2 + 0.5) * 1000.0           # 1 km grid around the pole
+    sy = (np.arange(n) - n / 2 + 0.5) * 1000.0 - 2.6e6   # shifted south: 55-80 N
+    ox, oy = 1200, 900
+    lon = np.linspace(-25, 25, ox)
+    lat = np.linspace(52, 78, oy)
+    qx, qy = po.project_axes(geo, stere, np.radians(lon), np.radians(lat))
+    px = fa.points2position_host(qx, sx)
+    py = fa.points2position_host(qy, sy)
+    yy, xx = np.meshgrid(sy, sx, indexing="ij")
+    ang = 1e-6 * xx + 2e-6 * yy
+    u = (10 * np.cos(ang)).astype(np.float32)[None]
+    v = (10 * np.sin(ang)).astype(np.float32)[None]
+    u[0, 500:900, 1000:1500] = np.nan  # a hole in both components (e.g. masked land)
+    v[0, 500:900, 1000:1500] = np.nan
+    from test_oracle_kats import _rotation_matrix
+    m = _rotation_matrix(stere, geo, lon, lat, oracle.LONGITUDE, oracle.LATITUDE)
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, n, n, ox, oy)
+    vec = fa.VectorPlan(m, ox, oy)
+    post = [fa.creepfill2d_process(20, 2)]
+    gu = fa.regrid_slice_host(plan, u, counterpart=v, vec=vec, isXComponent=True, post=post)
+    gv = fa.regrid_slice_host(plan, v, counterpart=u, vec=vec, isXComponent=False, post=post)
+    iu = oracle.interpolate_values(oracle.BILINEAR, px, py, u, n, n, ox, oy, nthreads=16)
+    iv = oracle.interpolate_values(oracle.BILINEAR, px, py, v, n, n, ox, oy, nthreads=16)
+    ru, rv = oracle.vector_reproject_values(m, iu, iv, ox, oy)
+    wu = oracle.creepfill2d(ru[0], 20, 2)[0]
+    wv = oracle.creepfill2d(rv[0], 20, 2)[0]
+    assert cases.same(gu[0], wu), cases.describe_mismatch(gu[0], wu)
+    assert cases.same(gv[0], wv), cases.describe_mismatch(gv[0], wv)
+    assert np.isnan(ru).any() and not np.isnan(gu).any()  # the fill closed the hole and the outside
+    ok = ~np.isnan(ru[0])
+    assert cases.same(gu[0][ok], ru[0][ok])               # defined cells are untouched by the fill
+    np.testing.assert_allclose(np.hypot(gu[0][ok], gv[0][ok]), np.hypot(iu[0][ok], iv[0][ok]), rtol=1e-5)  # length kept

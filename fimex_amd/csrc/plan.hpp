@@ -33,16 +33,15 @@ enum class Aggregate : int { Sum = 0, Mean = 1, Median = 2, Max = 3, Min = 4 };
 }  // namespace fimex_amd
 
 namespace fimex_amd {
-// LDS-staged form of a bilinear plan (staged.hip): per tile the source row segments to stream into
-// LDS, per output cell two 16-bit LDS offsets (stencil rows) and the float fractions.
+// LDS-staged form of a bilinear / bicubic plan (staged.hip): per tile the source row segments to stream into
+// LDS, per output cell the 16-bit LDS offsets of its stencil rows; the fractions are those of the gather plan.
 struct StagedPlan {
     bool valid = false;
     uint32_t tileW = 0, tileH = 0, per = 0, kmax = 0, tilesX = 0, nTiles = 0;
     size_t stagedCells = 0;  // source cells streamed per slice (16-byte granules, all tiles)
     DeviceArray<uint32_t> tileRows;
     DeviceArray<uint2> tileHdr;
-    DeviceArray<uint32_t> lds;
-    DeviceArray<float> xf, yf;
+    DeviceArray<uint32_t> ldsA, ldsB;  // LDS offsets of stencil rows 0|1 (and 2|3 for bicubic), 16 bits each
 };
 }  // namespace fimex_amd
 
@@ -80,8 +79,8 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
 void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 
 // staged.hip
-bool build_staged_bilinear(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
-void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
+void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 
 // forward.hip
 void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);

@@ -441,9 +441,11 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
     plan.info.undefinedCells = (size_t)h.undefined;
     plan.info.borderCells = (size_t)h.border;
     // bilinear: also the LDS-staged form (staged.hip); plans whose tiles do not fit keep the gather kernel only
-    if (plan.kind == PlanKind::Bilinear && tuning("STAGED", 1) != 0 && build_staged_bilinear(plan, d_px, d_py, stream)) {
-        const auto& s = plan.staged;
-        plan.info.planBytes = s.lds.bytes() + s.xf.bytes() + s.yf.bytes() + s.tileHdr.bytes() + (size_t)s.nTiles * 2 * 4 * 48;
+    if ((plan.kind == PlanKind::Bilinear || plan.kind == PlanKind::Bicubic) && tuning("STAGED", 1) != 0 &&
+        build_staged_plan(plan, d_px, d_py, stream)) {
+        const auto& s = plan.staged;  // the staged kernel reads LDS offsets instead of pos, plus the tile tables
+        plan.info.planBytes = plan.info.planBytes - plan.pos.bytes() + s.ldsA.bytes() + s.ldsB.bytes() + s.tileHdr.bytes() +
+                              (size_t)s.nTiles * 2 * 4 * 48;
     }
 }
 
@@ -452,9 +454,8 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
     if (nz == 0) return;
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
     // the staged kernel pays a per-tile set-up (row table, chunk list) that only amortises over a few slices
-    if (plan.kind == PlanKind::Bilinear && plan.staged.valid && tuning("STAGED", 1) != 0 &&
-        nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
-        launch_staged_bilinear(plan, d_in, nz, d_out, stream);
+    if (plan.staged.valid && tuning("STAGED", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
+        launch_staged_apply(plan, d_in, nz, d_out, stream);
         return;
     }
     dim3 grid;

@@ -1,20 +1,22 @@
-// LDS-staged bilinear regrid for gfx950 (the bandwidth path of the headline metric).
+// LDS-staged backward regrid (bilinear and bicubic) for gfx950: the bandwidth path of the headline metric.
 //
-// Same arithmetic as bilinear_apply in regrid.hip (src/interpolation.c:881-957), different data
-// movement.  A per-lane gather of the 2x2 stencil straight from global memory asks the memory system
-// for the same 128-byte lines several times (measured: 3x the ideal L2 requests, 1.6x the ideal fabric
-// reads on the 4000x3000 -> 2000x2000 rotated-pole case, profiles/r01_*), because a wave's lanes
-// stride through the source and neighbouring workgroups share lines but not their timing.  Here a
-// workgroup owns a TW x TH tile of OUTPUT cells; the SOURCE cells that tile needs form a sheared
-// band (the target grid is rotated against the source grid): per source row one contiguous x range.
-// The plan stores, per tile, that list of row segments (16-byte aligned, so the staged image is a
-// little larger than the cells actually read).  For every z slice the workgroup
-//   1. streams the segments from HBM with one 16-byte load per lane -- whole lines, each requested
-//      once per tile, fully coalesced -- into the next LDS buffer (double buffered: the loads for
-//      slice z+1 are in flight while slice z is interpolated),
-//   2. gathers the 2x2 stencils from LDS (ds_read2_b32 pairs) and writes 256 contiguous bytes of
-//      output per wave.
-// The per-output plan entry shrinks to two 16-bit LDS offsets + the two float fractions.
+// Same arithmetic as bilinear_apply / bicubic_apply in regrid.hip (src/interpolation.c:881-1028), different data
+// movement.  A per-lane gather of the stencil straight from global memory asks the memory system for the same
+// 128-byte lines several times (measured on the 4000x3000 -> 2000x2000 rotated-pole case, profiles/r01_*: 3x the
+// ideal L2 requests and 1.6x the ideal fabric reads for the 2x2 stencil; the 4x4 stencil ran at 17 % of the HBM
+// roofline), because a wave's lanes stride through the source and neighbouring workgroups share lines but not
+// their timing.  Here a workgroup owns a TW x TH tile of OUTPUT cells; the SOURCE cells that tile needs form a
+// sheared band (the target grid is rotated against the source grid): per source row one contiguous x range.  The
+// plan stores, per tile, that list of row segments (16-byte aligned, so the staged image is a little larger than
+// the cells actually read).  For every z slice the workgroup
+//   1. streams the segments HBM -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA: 1 KiB per wave instruction, whole
+//      lines, each requested once per tile, no VGPR round trip) into the other LDS buffer while
+//   2. the current buffer is interpolated: stencils come from LDS (ds_read2_b32 pairs), and every wave writes
+//      256 contiguous bytes of output per store, non-temporal.
+// The per-output plan entry is two (bilinear) or four (bicubic) 16-bit LDS row offsets; the fractions are the ones of
+// the gather plan.  Measured and kept out (profiles/r01_sweep*.log): register staging instead of LDS-DMA (equal),
+// 2-4 slices of prefetch depth (equal), non-temporal loads (-15 %), plain stores (-6 %), XCD-contiguous or striped
+// tile orders (equal or worse than plain round-robin).
 #include "plan.hpp"
 
 namespace fimex_amd {
@@ -29,46 +31,50 @@ __device__ __forceinline__ bool usable(double x, double y)
     return (fabs(x) < lim) && (fabs(y) < lim);
 }
 
-constexpr int kMaxRows = 160;      // source rows one tile may span
+constexpr int kMaxRows = 160;  // source rows one tile may span
 
 struct TileGeom {
     uint32_t outX, outY;
-    uint32_t tileW, tileH;     // output cells per tile (tileW * tileH = 256 * outputs per lane)
+    uint32_t tileW, tileH;  // output cells per tile (tileW * tileH = 256 * outputs per lane)
     uint32_t tilesX, nTiles;
-    uint32_t capChunks;        // 16-byte chunks one LDS buffer holds
+    uint32_t capChunks;     // 16-byte chunks one LDS buffer holds
 };
 
-// classification of one output cell: which source cells it reads (src/interpolation.c:883-954)
+// which source cells one output cell reads: columns xa..xb of rows ya..yb (inclusive)
 struct CellNeed {
     bool valid;
-    int64_t xa, xb, ya, yb;    // inclusive ranges of source columns / rows
-    float xf, yf;              // fractions, sign bit = nearest neighbour in that direction
+    int64_t xa, xb, ya, yb;
 };
 
+// STENCIL 2: bilinear incl. its border branches (src/interpolation.c:883-954); 4: bicubic (:970-976)
+template <int STENCIL>
 __device__ CellNeed classify(double x, double y, int64_t ix, int64_t iy)
 {
     CellNeed c{};
     c.valid = false;
     if (!usable(x, y)) return c;
-    const double flx = floor(x), fly = floor(y);
-    const int64_t x0 = (int64_t)flx, y0 = (int64_t)fly;
-    c.xf = (float)(x - flx);
-    c.yf = (float)(y - fly);
+    const int64_t x0 = (int64_t)floor(x), y0 = (int64_t)floor(y);
+    if (STENCIL == 4) {
+        if ((1 <= x0) && (x0 + 2 < ix) && (1 <= y0) && (y0 + 2 < iy)) {
+            c.valid = true; c.xa = x0 - 1; c.xb = x0 + 2; c.ya = y0 - 1; c.yb = y0 + 2;
+        }
+        return c;
+    }
     const bool xlin = (0 <= x0) && (x0 + 1 < ix);
     const bool ylin = (0 <= y0) && (y0 + 1 < iy);
     if (xlin && ylin) {
         c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = y0; c.yb = y0 + 1;
     } else if (xlin) {
         const int64_t ry = (int64_t)round(y);
-        if (0 <= ry && ry < iy) { c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = c.yb = ry; c.yf = -1.f; }
+        if (0 <= ry && ry < iy) { c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = c.yb = ry; }
     } else {
         const int64_t rx = (int64_t)round(x);
         if (0 <= rx && rx < ix) {
             if (ylin) {
-                c.valid = true; c.xa = c.xb = rx; c.ya = y0; c.yb = y0 + 1; c.xf = -1.f;
+                c.valid = true; c.xa = c.xb = rx; c.ya = y0; c.yb = y0 + 1;
             } else {
                 const int64_t ry = (int64_t)round(y);
-                if (0 <= ry && ry < iy) { c.valid = true; c.xa = c.xb = rx; c.ya = c.yb = ry; c.xf = -1.f; c.yf = -1.f; }
+                if (0 <= ry && ry < iy) { c.valid = true; c.xa = c.xb = rx; c.ya = c.yb = ry; }
             }
         }
     }
@@ -76,17 +82,17 @@ __device__ CellNeed classify(double x, double y, int64_t ix, int64_t iy)
 }
 
 struct BuildCounters {
-    unsigned long long undefined, border, overflow, stagedChunks;
+    unsigned long long overflow, stagedChunks;
 };
 
-// One workgroup per tile: finds the row segments the tile reads and the LDS offsets of every output.
-// tileRows[tile][2*i] = global cell offset of segment i, [2*i+1] = first chunk index of segment i (prefix sum);
-// tileHdr[tile] = {nr, totalChunks}.
-__global__ void __launch_bounds__(kBlock) build_tiles_bilinear(const double* __restrict__ px, const double* __restrict__ py,
-                                                               int64_t ix, int64_t iy, TileGeom g,
-                                                               uint32_t* __restrict__ tileRows, uint2* __restrict__ tileHdr,
-                                                               uint32_t* __restrict__ lds, float* __restrict__ xfr,
-                                                               float* __restrict__ yfr, BuildCounters* counters)
+// One workgroup per tile: finds the row segments the tile reads and the LDS offsets of every output's stencil rows.
+// tileRows[tile][2*i] = global cell offset of segment i, [2*i+1] = first chunk of segment i (prefix sum);
+// tileHdr[tile] = {rows, chunks}; ldsA[cell] = offsets (in floats) of stencil rows 0 | 1 << 16, ldsB: rows 2 | 3 << 16.
+template <int STENCIL>
+__global__ void __launch_bounds__(kBlock) build_tiles(const double* __restrict__ px, const double* __restrict__ py, int64_t ix,
+                                                      int64_t iy, TileGeom g, uint32_t* __restrict__ tileRows,
+                                                      uint2* __restrict__ tileHdr, uint32_t* __restrict__ ldsA,
+                                                      uint32_t* __restrict__ ldsB, BuildCounters* counters)
 {
     __shared__ int shRmin, shRmax;
     __shared__ int rowMin[kMaxRows], rowMax[kMaxRows];
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(kBlock) build_tiles_bilinear(const double* __r
     const uint32_t perLane = (g.tileW * g.tileH) / kBlock;
     if (threadIdx.x == 0) { shRmin = 0x7FFFFFFF; shRmax = -1; shOverflow = 0; }
     __syncthreads();
-    // lane owns column lx of rows ly, ly + rowsPerPass, ... of the tile (a wave covers 64 consecutive x)
+    // lane owns column lx of rows ly0, ly0 + rowsPerPass, ... of the tile (a wave covers 64 consecutive x)
     const uint32_t lx = threadIdx.x % g.tileW;
     const uint32_t rowsPerPass = kBlock / g.tileW;
     const uint32_t ly0 = threadIdx.x / g.tileW;
@@ -105,7 +111,7 @@ __global__ void __launch_bounds__(kBlock) build_tiles_bilinear(const double* __r
         const uint32_t x = tx * g.tileW + lx, y = ty * g.tileH + ly0 + k * rowsPerPass;
         if (x < g.outX && y < g.outY) {
             const size_t cell = (size_t)y * g.outX + x;
-            const CellNeed c = classify(px[cell], py[cell], ix, iy);
+            const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
             if (c.valid) { atomicMin(&shRmin, (int)c.ya); atomicMax(&shRmax, (int)c.yb); }
         }
     }
@@ -122,7 +128,7 @@ __global__ void __launch_bounds__(kBlock) build_tiles_bilinear(const double* __r
         const uint32_t x = tx * g.tileW + lx, y = ty * g.tileH + ly0 + k * rowsPerPass;
         if (x < g.outX && y < g.outY) {
             const size_t cell = (size_t)y * g.outX + x;
-            const CellNeed c = classify(px[cell], py[cell], ix, iy);
+            const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
             if (c.valid)
                 for (int64_t r = c.ya; r <= c.yb; ++r) {
                     atomicMin(&rowMin[r - rmin], (int)c.xa);
@@ -162,20 +168,20 @@ __global__ void __launch_bounds__(kBlock) build_tiles_bilinear(const double* __r
         const uint32_t x = tx * g.tileW + lx, y = ty * g.tileH + ly0 + k * rowsPerPass;
         if (x < g.outX && y < g.outY) {
             const size_t cell = (size_t)y * g.outX + x;
-            const CellNeed c = classify(px[cell], py[cell], ix, iy);
-            uint32_t packed = kInvalidPos;
+            const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+            uint32_t a = kInvalidPos, b = kInvalidPos;
             if (c.valid) {
-                const int ia = (int)(c.ya - rmin), ib = (int)(c.yb - rmin);
-                const uint32_t la = rowChunk[ia] * 4 + (uint32_t)(c.xa - rowMin[ia]);
-                const uint32_t lb = rowChunk[ib] * 4 + (uint32_t)(c.xa - rowMin[ib]);
-                packed = la | (lb << 16);
-                if ((__float_as_uint(c.xf) | __float_as_uint(c.yf)) >> 31) atomicAdd(&counters->border, 1ull);
-            } else {
-                atomicAdd(&counters->undefined, 1ull);
+                uint32_t off[4];
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = (c.ya + r <= c.yb) ? c.ya + r : c.yb;  // missing rows repeat the last one
+                    const int i = (int)(row - rmin);
+                    off[r] = rowChunk[i] * 4 + (uint32_t)(c.xa - rowMin[i]);
+                }
+                a = off[0] | (off[1] << 16);
+                b = off[2] | (off[3] << 16);
             }
-            lds[cell] = packed;
-            xfr[cell] = c.valid ? c.xf : 0.f;
-            yfr[cell] = c.valid ? c.yf : 0.f;
+            ldsA[cell] = a;
+            if (STENCIL == 4) ldsB[cell] = b;
         }
     }
 }
@@ -185,9 +191,12 @@ struct StagedArgs {
     float* out;
     const uint32_t* tileRows;
     const uint2* tileHdr;
-    const uint32_t* lds;
-    const float* xf;
+    const uint32_t* ldsA;
+    const uint32_t* ldsB;
+    const float* xf;    // bilinear fractions of the gather plan (sign bit = nearest neighbour in that direction)
     const float* yf;
+    const double* xfd;  // bicubic fractions
+    const double* yfd;
     TileGeom g;
     size_t inLayer;
     uint32_t nOut;
@@ -195,11 +204,6 @@ struct StagedArgs {
     uint32_t tilesPerXcd, xcdRemap;
     uint32_t ablate;  // diagnostics only (FIMEX_AMD_ABLATE): 1 = no source loads, 2 = no output stores
 };
-
-__device__ __forceinline__ float bilinear_point(float s00, float s01, float s10, float s11, float xf, float yf)
-{
-    return (1.f - yf) * ((1.f - xf) * s00 + xf * s01) + yf * ((1.f - xf) * s10 + xf * s11);  // interpolation.c:899-900
-}
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
@@ -209,23 +213,38 @@ __device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
 
 // One LDS-DMA wave instruction: 64 lanes x 16 bytes from per-lane buffer offsets to ldsBase + lane * 16.
 // (The builtin exists only in the device pass; the host pass of hipcc parses kernel bodies too.)
-template <int AUX>
 __device__ __forceinline__ void dma16(rsrc_t rs, float* ldsBase, uint32_t voff)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using lds_ptr = __attribute__((address_space(3))) void*;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, AUX);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 0);
 #else
     (void)rs; (void)ldsBase; (void)voff;
 #endif
 }
 
-// PER: outputs per lane; KMAX: 16-byte chunks per lane and slice (KMAX * 256 * 16 bytes = one LDS buffer).
-// DMA = true: the row segments go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no
-//   VGPR round trip and no ds_write); the next slice lands in the other buffer while this one is interpolated.
-// DMA = false: register staging, DEPTH slices in flight in VGPRs ahead of the one being interpolated.
-template <int PER, int KMAX, int DEPTH, bool DMA, int LDAUX = 0, int STAUX = 2>
-__global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
+// Keys kernel a = -0.5: rows of M/2 (src/interpolation.c:962-968), weights XM / MY (:977-1000)
+__device__ __forceinline__ void cubic_weights(double f, double w[4])
+{
+    const double M[4][4] = {{0.0, 1.0, 0.0, 0.0}, {-0.5, 0.0, 0.5, 0.0}, {1.0, -2.5, 2.0, -0.5}, {-0.5, 1.5, -1.5, 0.5}};
+    double X[4];
+    X[0] = 1;
+    X[1] = f;
+    X[2] = f * f;
+    X[3] = X[2] * f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += X[j] * M[j][i];
+        w[i] = s;
+    }
+}
+
+// STENCIL: 2 bilinear, 4 bicubic; PER: outputs per lane; KMAX: 16-byte chunks per lane and slice
+// (KMAX * 256 * 16 bytes = one LDS buffer).
+template <int STENCIL, int PER, int KMAX>
+__global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers of KMAX*256*4 floats (+ slack), then the row table
     constexpr uint32_t kBufFloats = KMAX * kBlock * 4 + 4;
@@ -233,18 +252,17 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     float* buf1 = smem + kBufFloats;
     uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + 2 * kBufFloats);  // [2 * nr]
 
-    // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an L2), so
-    //   xcdRemap 0: neighbouring tiles of a row land on different XCDs;
-    //   xcdRemap 1: each XCD owns one contiguous band of tile rows (neighbours share an L2, but the bands differ in work);
-    //   xcdRemap >= 2: tile rows are dealt to the XCDs in stripes of (xcdRemap - 1) rows: x-neighbours share an L2
-    //                  (their partial edge lines hit) and every XCD sees the same mix of cheap and expensive rows.
+    // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an L2):
+    //   xcdRemap 0: tiles in dispatch order (neighbours on different XCDs) -- the default, measured as good as any;
+    //   xcdRemap 1: each XCD owns one contiguous band of tile rows;
+    //   xcdRemap >= 2: tile rows dealt to the XCDs in stripes of (xcdRemap - 1) rows.
     const uint32_t b = blockIdx.x;
     uint32_t tile = b;
     if (a.xcdRemap == 1) {
         tile = (b % kXcds) * a.tilesPerXcd + b / kXcds;
     } else if (a.xcdRemap >= 2) {
-        const uint32_t stripe = (a.xcdRemap - 1) * a.g.tilesX;  // tiles per stripe
-        const uint32_t idx = b / kXcds;                         // position in this XCD's sequence
+        const uint32_t stripe = (a.xcdRemap - 1) * a.g.tilesX;
+        const uint32_t idx = b / kXcds;
         tile = ((idx / stripe) * kXcds + b % kXcds) * stripe + idx % stripe;
     }
     if (tile >= a.g.nTiles) return;
@@ -253,31 +271,39 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     const uint2 hdr = a.tileHdr[tile];
     const uint32_t nr = hdr.x, totalChunks = hdr.y;
 
-    // ---- per-lane plan: outputs and their LDS stencil offsets
+    // ---- per-lane plan: outputs, LDS byte offsets of their stencil rows, weights
     const uint32_t tx = tile % a.g.tilesX, ty = tile / a.g.tilesX;
     const uint32_t lx = threadIdx.x % a.g.tileW;
     const uint32_t rowsPerPass = kBlock / a.g.tileW;
     const uint32_t ly0 = threadIdx.x / a.g.tileW;
-    uint32_t cellOff[PER];  // byte offset of the output cell inside a slice; ~0u (not mine) is dropped by the bounds check
-    uint32_t la[PER], lb[PER];  // LDS byte offsets of the two stencil rows
-    float xf[PER], yf[PER];
+    uint32_t cellOff[PER];        // byte offset of the output cell inside a slice; ~0u (not mine) is dropped by the bounds check
+    uint32_t row[PER][STENCIL];   // LDS byte offsets of the stencil rows
+    float xf[PER], yf[PER];       // bilinear
+    double XM[PER][4], MY[PER][4];  // bicubic (unused and eliminated for bilinear)
     bool undef[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const uint32_t x = tx * a.g.tileW + lx, y = ty * a.g.tileH + ly0 + k * rowsPerPass;
         cellOff[k] = 0xFFFFFFFFu;
-        uint32_t packed = kInvalidPos;
+        uint32_t pa = kInvalidPos, pb = kInvalidPos;
         xf[k] = yf[k] = 0.f;
+        double fx = 0, fy = 0;
         if (x < a.g.outX && y < a.g.outY) {
             const uint32_t cell = y * a.g.outX + x;
             cellOff[k] = cell * 4u;
-            packed = a.lds[cell];
-            xf[k] = a.xf[cell];
-            yf[k] = a.yf[cell];
+            pa = a.ldsA[cell];
+            if (STENCIL == 4) { pb = a.ldsB[cell]; fx = a.xfd[cell]; fy = a.yfd[cell]; }
+            else { xf[k] = a.xf[cell]; yf[k] = a.yf[cell]; }
         }
-        undef[k] = packed == kInvalidPos;
-        la[k] = undef[k] ? 0u : (packed & 0xFFFFu) * 4u;  // undefined cells read LDS offset 0 and discard it
-        lb[k] = undef[k] ? 0u : (packed >> 16) * 4u;
+        undef[k] = pa == kInvalidPos;  // undefined cells read LDS offset 0 and discard it
+        row[k][0] = undef[k] ? 0u : (pa & 0xFFFFu) * 4u;
+        row[k][1] = undef[k] ? 0u : (pa >> 16) * 4u;
+        if (STENCIL == 4) {
+            row[k][2] = undef[k] ? 0u : (pb & 0xFFFFu) * 4u;
+            row[k][3] = undef[k] ? 0u : (pb >> 16) * 4u;
+            cubic_weights(fx, XM[k]);
+            cubic_weights(fy, MY[k]);
+        }
     }
     const uint32_t outBytes = a.nOut * 4u;
 
@@ -294,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     const uint32_t* rows = a.tileRows + (size_t)tile * 2 * kMaxRows;
     for (uint32_t i = threadIdx.x; i < 2 * nr; i += kBlock) shRows[i] = rows[i];
     __syncthreads();
-    uint32_t gOff[KMAX];  // byte offset of the chunk inside a source slice, ~0u = none (dropped by the bounds check)
+    uint32_t gOff[KMAX];  // byte offset of the chunk inside a source slice, ~0u = none (dropped by the bounds check: zeros)
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
         const uint32_t c = threadIdx.x + j * kBlock;
@@ -310,138 +336,92 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply_staged(StagedArgs a)
     }
 
     const uint32_t inBytes = (uint32_t)a.inLayer * 4u;
-
-// shared by both staging flavours: interpolate slice z of this tile from the LDS image `cur`
-#define FA_COMPUTE(z)                                                                                              \
-    {                                                                                                              \
-        const rsrc_t ro = make_rsrc(a.out + (size_t)(z) * a.nOut, (a.ablate & 2) ? 0u : outBytes);                \
-        const char* curb = reinterpret_cast<const char*>(cur);                                                     \
-        float s00[PER], s01[PER], s10[PER], s11[PER];                                                              \
-        _Pragma("unroll") for (int k = 0; k < PER; ++k) { /* all stencil reads first: 2 x ds_read2_b32 per output */ \
-            const float* pa = reinterpret_cast<const float*>(curb + la[k]);                                        \
-            const float* pb = reinterpret_cast<const float*>(curb + lb[k]);                                        \
-            s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];                                        \
-        }                                                                                                          \
-        _Pragma("unroll") for (int k = 0; k < PER; ++k) {                                                          \
-            const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;      \
-            /* interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911) */ \
-            const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];                                             \
-            const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];                                             \
-            const float inter = (1.f - yf[k]) * top + yf[k] * bot;                                                 \
-            const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]); /* nearest in x, linear in y (:931) */     \
-            float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);                                           \
-            r = undef[k] ? undefined_f() : r;                                                                      \
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, STAUX);                   \
-        }                                                                                                          \
-    }
-
-    if constexpr (DMA) {
-        // one wave instruction moves 64 chunks = 1 KiB: LDS destination = wave-uniform base + lane * 16
-        const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
-#define FA_DMA(dst, zz)                                                                                            \
-    {                                                                                                              \
-        const rsrc_t rs_ = make_rsrc(a.in + (size_t)(zz) * a.inLayer, (a.ablate & 1) ? 0u : inBytes);             \
-        _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                                           \
-            dma16<LDAUX>(rs_, (dst) + (waveChunk + j * kBlock) * 4, gOff[j]);                                      \
-    }
-        float* cur = buf0;
-        float* nxt = buf1;
-        FA_DMA(cur, z0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (uint32_t z = z0; z < z1; ++z) {
-            const bool more = z + 1 < z1;
-            if (more) FA_DMA(nxt, z + 1)
-            FA_COMPUTE(z)
-            // the DMA was issued before this slice's PER stores: wait for it, leave the stores in flight
-            if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            float* t = cur; cur = nxt; nxt = t;
-        }
-#undef FA_DMA
-        return;
-    }
-
-    using u4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
-    u4 stage[DEPTH][KMAX];
-
-#define FA_ISSUE(set, zz)                                                                       \
-    {                                                                                           \
-        const rsrc_t rs_ = make_rsrc(a.in + (size_t)(zz) * a.inLayer, (a.ablate & 1) ? 0u : inBytes); \
-        _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                        \
-            stage[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_, gOff[j], 0, 0);          \
-    }
-#define FA_COMMIT(set, dst)                                                                     \
-    {                                                                                           \
-        /* chunks past the tile's last one carry zeros (bounds-checked loads) into unused LDS */ \
-        _Pragma("unroll") for (int j = 0; j < KMAX; ++j)                                        \
-            reinterpret_cast<u4*>(dst)[threadIdx.x + j * kBlock] = stage[set][j];               \
-    }
-
-    // prologue: slices z0 .. z0+DEPTH-1 in flight, slice z0 committed to LDS
+    // one wave instruction moves 64 chunks = 1 KiB: LDS destination = wave-uniform base + lane * 16
+    const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
+    auto dma = [&](float* dst, uint32_t z) {
+        const rsrc_t rs = make_rsrc(a.in + (size_t)z * a.inLayer, (a.ablate & 1) ? 0u : inBytes);
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (z0 + d < z1) FA_ISSUE(d, z0 + d)
-    FA_COMMIT(0, buf0)
-    __syncthreads();
+        for (int j = 0; j < KMAX; ++j) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j]);
+    };
+
     float* cur = buf0;
     float* nxt = buf1;
-    for (uint32_t zb = z0; zb < z1; zb += DEPTH) {
+    dma(cur, z0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (uint32_t z = z0; z < z1; ++z) {
+        if (z + 1 < z1) dma(nxt, z + 1);
+        const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, (a.ablate & 2) ? 0u : outBytes);
+        const char* curb = reinterpret_cast<const char*>(cur);
+        if constexpr (STENCIL == 2) {
+            float s00[PER], s01[PER], s10[PER], s11[PER];
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const uint32_t z = zb + d;
-            if (z >= z1) break;
-            // register set d held slice z (already in LDS): refill it with slice z + DEPTH
-            if (z + DEPTH < z1) FA_ISSUE(d, z + DEPTH)
-            FA_COMPUTE(z)
-            if (z + 1 < z1) FA_COMMIT((d + 1) % DEPTH, nxt)
-            __syncthreads();
-            float* t = cur; cur = nxt; nxt = t;
+            for (int k = 0; k < PER; ++k) {  // all stencil reads first: 2 x ds_read2_b32 per output, no waits in between
+                const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
+                const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
+                s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
+                // interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911)
+                const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];
+                const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];
+                const float inter = (1.f - yf[k]) * top + yf[k] * bot;
+                const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
+                float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
+                r = undef[k] ? undefined_f() : r;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                float f[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* pr = reinterpret_cast<const float*>(curb + row[k][i]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[i][j] = pr[j];
+                }
+                float acc = 0;  // interpolation.c:1005: accumulates into the float output
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double xmf = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[i][j];  // :1015
+                    acc = (float)((double)acc + xmf * MY[k][i]);                    // :1019
+                }
+                const float r = undef[k] ? undefined_f() : acc;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+            }
         }
+        // the DMA was issued before this slice's PER stores: wait for it, leave the stores in flight
+        if (PER == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float* t = cur; cur = nxt; nxt = t;
     }
-#undef FA_ISSUE
-#undef FA_COMMIT
-#undef FA_COMPUTE
 }
 
-template <int PER, int KMAX, int DEPTH, bool DMA, int LDAUX = 0, int STAUX = 2>
+template <int STENCIL, int PER, int KMAX>
 void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
     constexpr size_t ldsBytes = 2 * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
     static bool attrSet = false;
     if (!attrSet) {
-        FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_apply_staged<PER, KMAX, DEPTH, DMA, LDAUX, STAUX>),
+        FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
         attrSet = true;
     }
-    bilinear_apply_staged<PER, KMAX, DEPTH, DMA, LDAUX, STAUX><<<grid, kBlock, ldsBytes, stream>>>(a);
+    staged_apply<STENCIL, PER, KMAX><<<grid, kBlock, ldsBytes, stream>>>(a);
 }
 
-template <int PER, int KMAX>
-void launch_staged_depth(const StagedArgs& a, dim3 grid, hipStream_t stream)
-{
-    if (tuning("STAGE_DMA", 1) != 0) {
-        if (PER == 4 && KMAX == 6) {  // cache-policy experiments (sweeps only)
-            const int ld = tuning("STAGE_LDAUX", 0), st = tuning("STAGE_STAUX", 2);
-            if (ld == 2 && st == 2) { launch_staged<4, 6, 1, true, 2, 2>(a, grid, stream); return; }
-            if (ld == 0 && st == 0) { launch_staged<4, 6, 1, true, 0, 0>(a, grid, stream); return; }
-            if (ld == 2 && st == 0) { launch_staged<4, 6, 1, true, 2, 0>(a, grid, stream); return; }
-        }
-        launch_staged<PER, KMAX, 1, true>(a, grid, stream);
-        return;
-    }
-    launch_staged<PER, KMAX, 1, false>(a, grid, stream);
-}
-
-}  // namespace
-
-namespace {
-
-bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream,
-                      uint32_t tileW, uint32_t per, uint32_t kmax)
+template <int STENCIL>
+bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream, uint32_t tileW,
+                      uint32_t per, uint32_t kmax)
 {
     TileGeom g{};
     g.outX = (uint32_t)plan.outX;
@@ -454,12 +434,11 @@ bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const dou
     const size_t n = plan.outX * plan.outY;
     DeviceArray<uint32_t> tileRows((size_t)g.nTiles * 2 * kMaxRows);
     DeviceArray<uint2> tileHdr(g.nTiles);
-    DeviceArray<uint32_t> lds(n);
-    DeviceArray<float> xf(n), yf(n);
+    DeviceArray<uint32_t> ldsA(n), ldsB(STENCIL == 4 ? n : 0);
     DeviceArray<BuildCounters> counters(1);
     FA_HIP(hipMemsetAsync(counters.get(), 0, sizeof(BuildCounters), stream));
-    build_tiles_bilinear<<<g.nTiles, kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, g, tileRows.get(),
-                                                          tileHdr.get(), lds.get(), xf.get(), yf.get(), counters.get());
+    build_tiles<STENCIL><<<g.nTiles, kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, g, tileRows.get(),
+                                                         tileHdr.get(), ldsA.get(), ldsB.get(), counters.get());
     FA_HIP(hipGetLastError());
     BuildCounters h{};
     FA_HIP(hipMemcpyAsync(&h, counters.get(), sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -474,9 +453,8 @@ bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const dou
     plan.staged.stagedCells = (size_t)h.stagedChunks * 4;
     plan.staged.tileRows = std::move(tileRows);
     plan.staged.tileHdr = std::move(tileHdr);
-    plan.staged.lds = std::move(lds);
-    plan.staged.xf = std::move(xf);
-    plan.staged.yf = std::move(yf);
+    plan.staged.ldsA = std::move(ldsA);
+    plan.staged.ldsB = std::move(ldsB);
     plan.staged.valid = true;
     return true;
 }
@@ -485,22 +463,31 @@ bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const dou
 
 // Chooses the smallest LDS budget whose tiles all fit; plans without spatial coherence (or with a source row length
 // that breaks the 16-byte alignment of row starts) keep only the gather kernel.
-bool build_staged_bilinear(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
 {
     if (plan.inX % 4 != 0) return false;
     const uint32_t tw = (uint32_t)tuning("STAGE_TW", 64);
     if (!(tw == 32 || tw == 64 || tw == 128 || tw == 256)) return false;
     const int forcedPer = tuning("STAGE_PER", 0), forcedK = tuning("STAGE_K", 0);
-    const uint32_t shapes[4][2] = {{4, 4}, {4, 6}, {8, 8}, {8, 12}};  // {outputs per lane, chunks per lane}
-    for (const auto& sh : shapes) {
-        if (forcedPer && (uint32_t)forcedPer != sh[0]) continue;
-        if (forcedK && (uint32_t)forcedK != sh[1]) continue;
-        if (try_build_staged(plan, d_px, d_py, stream, tw, sh[0], sh[1])) return true;
+    if (plan.kind == PlanKind::Bilinear) {
+        const uint32_t shapes[4][2] = {{4, 4}, {4, 6}, {8, 8}, {8, 12}};  // {outputs per lane, chunks per lane}
+        for (const auto& sh : shapes) {
+            if (forcedPer && (uint32_t)forcedPer != sh[0]) continue;
+            if (forcedK && (uint32_t)forcedK != sh[1]) continue;
+            if (try_build_staged<2>(plan, d_px, d_py, stream, tw, sh[0], sh[1])) return true;
+        }
+    } else if (plan.kind == PlanKind::Bicubic) {
+        const uint32_t shapes[4][2] = {{2, 3}, {2, 4}, {4, 6}, {4, 8}};
+        for (const auto& sh : shapes) {
+            if (forcedPer && (uint32_t)forcedPer != sh[0]) continue;
+            if (forcedK && (uint32_t)forcedK != sh[1]) continue;
+            if (try_build_staged<4>(plan, d_px, d_py, stream, tw, sh[0], sh[1])) return true;
+        }
     }
     return false;
 }
 
-void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
 {
     const auto& s = plan.staged;
     StagedArgs a{};
@@ -508,9 +495,12 @@ void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in
     a.out = d_out;
     a.tileRows = s.tileRows.get();
     a.tileHdr = s.tileHdr.get();
-    a.lds = s.lds.get();
-    a.xf = s.xf.get();
-    a.yf = s.yf.get();
+    a.ldsA = s.ldsA.get();
+    a.ldsB = s.ldsB.get();
+    a.xf = plan.xf.get();
+    a.yf = plan.yf.get();
+    a.xfd = plan.xfd.get();
+    a.yfd = plan.yfd.get();
     a.g.outX = (uint32_t)plan.outX;
     a.g.outY = (uint32_t)plan.outY;
     a.g.tileW = s.tileW;
@@ -525,7 +515,7 @@ void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in
     if (zpb < 1) zpb = 1;
     if (zpb > nz) zpb = (uint32_t)nz;
     a.zPerBlock = zpb;
-    a.xcdRemap = (uint32_t)tuning("XCD", 0);  // measured: plain round-robin is as good as any remap here (profiles/)
+    a.xcdRemap = (uint32_t)tuning("XCD", 0);
     a.ablate = (uint32_t)tuning("ABLATE", 0);
     a.tilesPerXcd = (uint32_t)ceil_div(s.nTiles, kXcds);
     uint32_t gridX = a.tilesPerXcd * kXcds;
@@ -536,10 +526,24 @@ void launch_staged_bilinear(const fimex_amd_regrid_plan& plan, const float* d_in
     const size_t chunks = ceil_div(nz, (size_t)zpb);
     FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
     const dim3 grid(gridX, (uint32_t)chunks, 1);
-    if (s.per == 4 && s.kmax == 4) launch_staged_depth<4, 4>(a, grid, stream);
-    else if (s.per == 4 && s.kmax == 6) launch_staged_depth<4, 6>(a, grid, stream);
-    else if (s.per == 8 && s.kmax == 8) launch_staged_depth<8, 8>(a, grid, stream);
-    else launch_staged_depth<8, 12>(a, grid, stream);
+    const uint32_t key = s.per * 100 + s.kmax;
+    if (plan.kind == PlanKind::Bilinear) {
+        switch (key) {
+        case 404: launch_staged<2, 4, 4>(a, grid, stream); break;
+        case 406: launch_staged<2, 4, 6>(a, grid, stream); break;
+        case 808: launch_staged<2, 8, 8>(a, grid, stream); break;
+        case 812: launch_staged<2, 8, 12>(a, grid, stream); break;
+        default: throw Error("staged bilinear: unexpected tile shape");
+        }
+    } else {
+        switch (key) {
+        case 203: launch_staged<4, 2, 3>(a, grid, stream); break;
+        case 204: launch_staged<4, 2, 4>(a, grid, stream); break;
+        case 406: launch_staged<4, 4, 6>(a, grid, stream); break;
+        case 408: launch_staged<4, 4, 8>(a, grid, stream); break;
+        default: throw Error("staged bicubic: unexpected tile shape");
+        }
+    }
     FA_HIP(hipGetLastError());
 }
 

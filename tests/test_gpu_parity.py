@@ -61,19 +61,23 @@ def test_backward_ragged_z_counts(fa, method, nz):
     assert cases.same(got, want), cases.describe_mismatch(got, want)
 
 
+@pytest.mark.parametrize("method", [oracle.BILINEAR, oracle.BICUBIC])
 @pytest.mark.parametrize("shape", [(400, 300, 200, 200, 10), (1000, 700, 333, 257, 7), (128, 96, 640, 480, 3), (64, 2000, 50, 300, 5)])
-@pytest.mark.parametrize("knobs", [{"STAGED": "0"}, {"STAGED": "1"}, {"STAGED": "1", "STAGE_TW": "128", "STAGE_PER": "8", "STAGE_K": "8"},
-                                   {"STAGED": "1", "STAGE_TW": "32", "STAGE_K": "6", "STAGE_ZPB": "3"}])
-def test_bilinear_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, shape, knobs):
-    """Both bilinear kernels (per-lane gather, LDS-staged tiles) on source widths that allow staging (inX % 4 == 0):
-    shrinking (several source cells per target cell), magnifying, and strongly anisotropic geometries."""
+@pytest.mark.parametrize("knobs", [{"STAGED": "0"}, {"STAGED": "1"}, {"STAGED": "1", "STAGE_TW": "128"},
+                                   {"STAGED": "1", "STAGE_TW": "32", "STAGE_ZPB": "3"},
+                                   {"STAGED": "1", "STAGE_TW": "256", "STAGE_ZPB": "1", "XCD": "1"},
+                                   {"STAGED": "1", "XCD": "3", "STAGED_MIN_NZ": "1"}])
+def test_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, method, shape, knobs):
+    """Both kernels of bilinear and bicubic (per-lane gather, LDS-staged tiles) on source widths that allow staging
+    (inX % 4 == 0): shrinking (several source cells per target cell), magnifying, and strongly anisotropic geometries,
+    different tile shapes, z chunkings and tile orders."""
     inX, inY, outX, outY, nz = shape
     for k, v in knobs.items():
         monkeypatch.setenv("FIMEX_AMD_" + k, v)
     px, py = cases.backward_positions(inX, inY, outX, outY, seed=inX + outX)
     f = cases.field(nz, inY, inX, seed=3)
-    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
-    got = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY).apply_host(f)
+    want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    got = fa.RegridPlan(method, px, py, inX, inY, outX, outY).apply_host(f)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
 
 

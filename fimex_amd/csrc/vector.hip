@@ -99,9 +99,42 @@ __global__ void __launch_bounds__(kBlock) rotate_direction(VecArgs a)
     const uint32_t z0 = blockIdx.y * a.zPerBlock;
     const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
     const double phiDeg = kRadToDeg * a.phi[i];
-    for (uint32_t z = z0; z < z1; ++z) {
-        float* p = a.u + (size_t)z * a.layer + i;
-        *p = rotate_angle(*p, phiDeg);
+    float* p = a.u + (size_t)z0 * a.layer + i;
+    uint32_t z = z0;
+    for (; z + 4 <= z1; z += 4, p += (size_t)4 * a.layer) {  // four slices in flight
+        const float a0 = p[0], a1 = p[a.layer], a2 = p[(size_t)2 * a.layer], a3 = p[(size_t)3 * a.layer];
+        p[0] = rotate_angle(a0, phiDeg);
+        p[a.layer] = rotate_angle(a1, phiDeg);
+        p[(size_t)2 * a.layer] = rotate_angle(a2, phiDeg);
+        p[(size_t)3 * a.layer] = rotate_angle(a3, phiDeg);
+    }
+    for (; z < z1; ++z, p += a.layer) *p = rotate_angle(*p, phiDeg);
+}
+
+// layer % 4 == 0 and a 16-byte aligned base: four cells per lane
+__global__ void __launch_bounds__(kBlock) rotate_direction_vec4(VecArgs a)
+{
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q * 4 >= a.layer) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    double pd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pd[k] = kRadToDeg * a.phi[q * 4 + k];
+    float4* p = reinterpret_cast<float4*>(a.u + (size_t)z0 * a.layer) + q;
+    const size_t stride = a.layer / 4;
+    uint32_t z = z0;
+    for (; z + 2 <= z1; z += 2, p += 2 * stride) {
+        float4 v0 = p[0], v1 = p[stride];
+        v0.x = rotate_angle(v0.x, pd[0]); v0.y = rotate_angle(v0.y, pd[1]); v0.z = rotate_angle(v0.z, pd[2]); v0.w = rotate_angle(v0.w, pd[3]);
+        v1.x = rotate_angle(v1.x, pd[0]); v1.y = rotate_angle(v1.y, pd[1]); v1.z = rotate_angle(v1.z, pd[2]); v1.w = rotate_angle(v1.w, pd[3]);
+        p[0] = v0;
+        p[stride] = v1;
+    }
+    for (; z < z1; ++z, p += stride) {
+        float4 v0 = p[0];
+        v0.x = rotate_angle(v0.x, pd[0]); v0.y = rotate_angle(v0.y, pd[1]); v0.z = rotate_angle(v0.z, pd[2]); v0.w = rotate_angle(v0.w, pd[3]);
+        p[0] = v0;
     }
 }
 
@@ -161,9 +194,12 @@ void launch_vector_direction(const fimex_amd_vector_plan& plan, float* d_angles,
 {
     if (oz == 0) return;
     FA_REQUIRE(oz <= 0xFFFFFFFFu, "too many slices");
+    const size_t layer = plan.ox * plan.oy;
+    const bool vec4 = (layer % 4 == 0) && (reinterpret_cast<uintptr_t>(d_angles) % 16 == 0);
     dim3 grid;
-    const VecArgs a = make_args(plan, d_angles, nullptr, oz, 1, grid);
-    rotate_direction<<<grid, kBlock, 0, stream>>>(a);
+    const VecArgs a = make_args(plan, d_angles, nullptr, oz, vec4 ? 4 : 1, grid);
+    if (vec4) rotate_direction_vec4<<<grid, kBlock, 0, stream>>>(a);
+    else rotate_direction<<<grid, kBlock, 0, stream>>>(a);
     FA_HIP(hipGetLastError());
 }
 

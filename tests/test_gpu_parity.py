@@ -196,7 +196,8 @@ def test_vector_rotation_90_degrees(fa):
     assert np.all(np.abs(gu + v) < 1e-4) and np.all(np.abs(gv - u) < 1e-4)
 
 
-@pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2)])
+@pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2), (4, 4, 1), (5, 70, 1), (300, 200, 2),
+                                   (64, 66, 1), (33, 1200, 1), (1000, 131, 1)])
 @pytest.mark.parametrize("params", [(4.0, 1.6, 100), (0.5, 1.0, 23), (4.0, 1.9, 3), (1e-9, 1.6, 41)])
 def test_fill2d_matches_oracle(fa, shape, params):
     nx, ny, nz = shape
@@ -225,6 +226,16 @@ def test_creepfill_matches_oracle(fa, shape, params):
         wantv, wnv, rc = oracle.creepfillval2d(f[z], 271.25, repeat, weight)
         assert rc == oracle.OK and nchv[z] == wnv
         assert cases.same(gotv[z], wantv), "slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))
+
+
+def test_fill2d_both_kernels_agree(fa, monkeypatch):
+    """The systolic row-band kernel and the anti-diagonal wavefront kernel are two implementations of the same order."""
+    f = cases.holes(2, 150, 210, seed=77)
+    monkeypatch.setenv("FIMEX_AMD_FILL_V2", "1")
+    a, na = fa.fill2d_host(f, 4.0, 1.6, 60)
+    monkeypatch.setenv("FIMEX_AMD_FILL_V2", "0")
+    b, nb = fa.fill2d_host(f, 4.0, 1.6, 60)
+    assert na == nb and cases.same(a, b)
 
 
 def test_fills_leave_complete_and_empty_slices_alone(fa):

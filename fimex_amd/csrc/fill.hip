@@ -21,7 +21,6 @@ namespace fimex_amd {
 namespace {
 
 constexpr int kFillBlock = 1024;
-constexpr int kTile = 4096;  // floats staged in LDS per serial-sum step
 
 struct SliceStats {
     unsigned long long nUndef;
@@ -31,41 +30,63 @@ struct SliceStats {
 };
 
 // sum of the defined values in scan order, double accumulator (interpolation.c:1256-1264, 1502-1513);
-// mode 1: sum of |v - average| instead (:1288-1299).  Every lane of wave 0 runs the same chain.
-template <int BLOCK = kFillBlock>
-__device__ double serial_sum(const float* __restrict__ f, size_t total, int mode, double average, float* lds,
-                             unsigned long long* nUndefOut)
+// mode 1: sum of |v - average| instead (:1288-1299); mode 2: only count the undefined cells.
+//
+// The additions form one dependent chain -- that is the point: the reference's order, hence its rounding.  All
+// else is taken off the chain: waves 1.. turn tile t+1 into ready double addends in LDS (undefined -> +0.0, which
+// leaves a sum that started at +0.0 unchanged; padding likewise) and count the undefined cells, while wave 0 walks
+// tile t with nothing but 16-byte LDS reads and v_add_f64.  buf: 2 * kSumTile doubles of LDS.
+constexpr int kSumTile = 2048;
+
+__device__ __forceinline__ double sum_addend(float v, int mode, double average, unsigned int& nUndef)
 {
-    // The additions form one dependent chain (that is the point: the reference's order).  Everything around it is
-    // taken off the chain: tiles are staged by the whole workgroup, wave 0 reads 8 values per LDS instruction pair
-    // and prepares the 8 addends (NaN -> +0.0, which leaves a sum that started at +0.0 unchanged) before adding them.
+    const bool undef = isnan(v);
+    nUndef += undef;
+    return undef ? 0.0 : (mode == 0 ? (double)v : fabs((double)v - average));
+}
+
+template <int BLOCK = kFillBlock>
+__device__ double serial_sum(const float* __restrict__ f, size_t total, int mode, double average, double* buf,
+                             unsigned long long* nUndefOut, unsigned chainLanes = kWave)
+{
+    __shared__ unsigned long long shCount;
+    constexpr int kProducers = BLOCK - kWave;
+    const size_t nTiles = (total + kSumTile - 1) / kSumTile;
+    unsigned int myUndef = 0;
     double sum = 0;
-    unsigned long long nUndef = 0;
-    for (size_t base = 0; base < total; base += kTile) {
-        const size_t len = (total - base < (size_t)kTile) ? total - base : (size_t)kTile;
-        __syncthreads();
-        for (size_t i = threadIdx.x; i < (size_t)kTile; i += BLOCK) lds[i] = (i < len) ? f[base + i] : __uint_as_float(0x7fc00000u);
-        __syncthreads();
+    if (threadIdx.x == 0) shCount = 0;
+    // tile 0 by everybody
+    for (size_t i = threadIdx.x; i < (size_t)kSumTile; i += BLOCK)
+        buf[i] = (i < total) ? sum_addend(f[i], mode, average, myUndef) : 0.0;
+    __syncthreads();
+    for (size_t t = 0; t < nTiles; ++t) {
         if (threadIdx.x < kWave) {
-            const float4* t4 = reinterpret_cast<const float4*>(lds);
-            const size_t groups = (len + 7) / 8;  // the tile is padded with NaN: padding adds +0.0 and is not counted
-            for (size_t g = 0; g < groups; ++g) {
-                const float4 a = t4[2 * g], b = t4[2 * g + 1];
-                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                double t[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool undef = isnan(v[k]);
-                    nUndef += undef;
-                    t[k] = undef ? 0.0 : (mode == 0 ? (double)v[k] : fabs((double)v[k] - average));
+            if (mode != 2 && threadIdx.x < chainLanes) {
+                const double2* b2 = reinterpret_cast<const double2*>(buf + (t & 1) * kSumTile);
+                double2 q0 = b2[0], q1 = b2[1], q2 = b2[2], q3 = b2[3];
+#pragma unroll 2
+                for (int g = 1; g <= kSumTile / 8; ++g) {  // the next 8 addends are read while these 8 are added
+                    const int h = (g < kSumTile / 8) ? g : 0;
+                    const double2 n0 = b2[4 * h], n1 = b2[4 * h + 1], n2 = b2[4 * h + 2], n3 = b2[4 * h + 3];
+                    sum += q0.x; sum += q0.y; sum += q1.x; sum += q1.y;
+                    sum += q2.x; sum += q2.y; sum += q3.x; sum += q3.y;
+                    q0 = n0; q1 = n1; q2 = n2; q3 = n3;
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sum += t[k];
             }
-            nUndef -= (groups * 8 - len);  // the NaN padding of the last group
+        } else if (t + 1 < nTiles) {
+            const size_t base = (t + 1) * kSumTile;
+            double* dst = buf + ((t + 1) & 1) * kSumTile;
+            for (size_t i = threadIdx.x - kWave; i < (size_t)kSumTile; i += kProducers)
+                dst[i] = (base + i < total) ? sum_addend(f[base + i], mode, average, myUndef) : 0.0;
         }
+        __syncthreads();
     }
-    if (nUndefOut) *nUndefOut = nUndef;
+    if (nUndefOut) {
+        if (myUndef) atomicAdd(&shCount, (unsigned long long)myUndef);
+        __syncthreads();
+        *nUndefOut = shCount;
+        __syncthreads();
+    }
     return sum;  // valid in wave 0
 }
 
@@ -81,7 +102,7 @@ struct Fill2dArgs {
 
 __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
 {
-    __shared__ __align__(16) float lds[kTile];
+    __shared__ __align__(16) double lds[2 * kSumTile];
     __shared__ double shAverage, shCrit;
     __shared__ unsigned long long shUndef;
     const uint32_t nx = a.nx, ny = a.ny;
@@ -197,6 +218,7 @@ struct Fill2dV2Args {
     uint32_t nx, ny, mws;
     float relaxCrit, corrEff;
     unsigned long long maxLoop;
+    uint32_t sumLanes;
 };
 
 // value of lane l-1 (lane 0 keeps its own): one DPP move, "wave_shr:1" (0x138), no LDS round trip
@@ -286,6 +308,16 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&hand.consumed[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // Every 16th boundary (band 15 -> 16, 31 -> 32, ...) goes through global memory instead: the wave of band b + 1 is
+    // still busy with band b - 15 there, so a bounded LDS window would close a cycle of waiting waves on wide grids.
+    // The producer's flush already writes the row; it only has to publish how far its stores have completed.
+    const bool hasBelow = y0 + nrow < ny - 1;
+    const bool outGlobal = hasBelow && (b % kV2Waves) == kV2Waves - 1;
+    const bool inGlobal = b > 0 && (b % kV2Waves) == 0;
+    auto wait_above = [&](uint32_t k) {
+        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
+        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    };
     // block k (columns 64k .. 64k+63) of the row above from the hand-off of band b - 1
     auto take_above = [&](uint32_t k) -> float {
         const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
@@ -304,7 +336,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     load_chunk(1);
     commit_chunk(1);
     load_chunk(2);
-    float upCur = (b == 0) ? load_block(0, 0) : take_above(0), upLd = 0.f;
+    float upCur, upLd = 0.f;
+    if (b == 0) upCur = load_block(0, 0);
+    else if (inGlobal) { wait_above(0); upCur = load_block(0, 0); }
+    else upCur = take_above(0);
     float downA = load_block(nrow + 1, 0), downB = downA, downLd = 0.f;  // current / next (landed) / in flight
     uint32_t downIssued = 0;
     bool downLdValid = false;
@@ -317,6 +352,11 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         const uint32_t xpc = c * kCh;
         if (c > 0) {
             // ---- event at the start of chunk c
+            if (outGlobal && xpc > L) {  // stores of the previous event (chunk c - 2) have landed: columns < 16 (c - 1) - L of the last row
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0 && xpc - kCh > L)
+                    __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             flush_chunk(c - 1);      // results of the chunk just finished -> global (never waited for)
             commit_chunk(c + 1);     // loaded one event ago, into the ring slot the flush has just read
             load_chunk(c + 2);       // consumed at the next event
@@ -326,10 +366,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 mwLd = mrow[min(c / 2 + 2, mws - 1)];
             }
             // publish how far the last row has got, and do not run more than the hand-off window ahead of the band below
-            if (xpc > L) {
+            if (xpc > L && !outGlobal) {
                 if (lane == 0)
                     __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (y0 + nrow < ny - 1) {  // there is a band below
+                if (hasBelow) {
                     const unsigned int limit = xpc + kCh - L;  // columns < limit are written during this chunk
                     while (true) {
                         const unsigned int cns = __hip_atomic_load(&hand.consumed[slotOut], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -340,10 +380,13 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             }
             // row above: lane 0 is at column x'
             if ((xpc & 63) == 0) {
-                if (b == 0) upCur = upLd;  // border row 0: from global, requested two chunks ago
+                if (b == 0 || inGlobal) upCur = upLd;  // from global, requested two chunks ago
                 else upCur = take_above(xpc >> 6);
             }
-            if (b == 0 && ((xpc + 2 * kCh) & 63) == 0) upLd = load_block(0, (xpc + 2 * kCh) >> 6);
+            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
+                if (inGlobal) wait_above((xpc + 2 * kCh) >> 6);
+                upLd = load_block(0, (xpc + 2 * kCh) >> 6);
+            }
             // row below: the last lane is at column x' - L
             if (downLdValid) { downB = downLd; downLdValid = false; }
             if (xpc + 3 * kCh > L) {
@@ -379,6 +422,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         }
     }
     flush_chunk(nChunks - 1);
+    if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, C + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -404,7 +448,7 @@ __global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 
     unsigned long long nUndef = 0;
-    const double sum = serial_sum<kV2Threads>(f, total, 0, 0., smem, &nUndef);
+    const double sum = serial_sum<kV2Threads>(f, total, 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumLanes);
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -417,7 +461,7 @@ __global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
     const unsigned long long nDef = total - nUndef;
     if (nDef == 0 || nUndef == 0) return;
     const double average = shAverage;
-    const double dev = serial_sum<kV2Threads>(f, total, 1, average, smem, nullptr);
+    const double dev = serial_sum<kV2Threads>(f, total, 1, average, reinterpret_cast<double*>(smem), nullptr, a.sumLanes);
     if (threadIdx.x == 0) shCrit = (double)a.relaxCrit * (dev / (double)nDef);
     __syncthreads();
     const double crit = shCrit;
@@ -502,7 +546,7 @@ struct CreepArgs {
 
 __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
 {
-    __shared__ __align__(16) float lds[kTile];
+    __shared__ __align__(16) double lds[2 * kSumTile];
     __shared__ unsigned long long shUndef;
     __shared__ float shDefault;
     __shared__ unsigned int shChanged;
@@ -514,7 +558,7 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
     SliceStats* st = a.stats + blockIdx.x;
 
     unsigned long long nUndef = 0;
-    const double sum = serial_sum(f, total, 0, 0., lds, &nUndef);
+    const double sum = serial_sum(f, total, a.useDefault ? 2 : 0, 0., lds, &nUndef);  // a default value needs no average
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -606,6 +650,385 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
     }
 }
 
+// ------------------------------------------------------------------ creep fill, systolic version
+// Same row-band pipeline as fill2d_kernel_v2 (lane = row, skewed columns, LDS ring, LDS hand-off between bands).
+// The reference's per-cell state (:1389-1421) is folded into bit masks in the same skewed layout as the rings:
+//   D  cell was defined on entry                      w = setWeight, r = repeat, never updated
+//   U  cell has been updated at least once            w = 1
+// A cell that starts being updated in sweep s is updated in every sweep s .. s + repeat - 1 (its neighbours never
+// lose their weight), so "r[p] < repeat" in sweep l is "p is not in U as of sweep l - repeat": U is kept for the
+// last repeat + 1 sweeps instead of a counter per cell.  Weights travel as floats (0, 1, setWeight: all exact).
+constexpr int kHandWC = 128;  // hand-off window of the creep kernel: values and weight codes share the LDS left
+
+struct CreepV2Args {
+    float* field;
+    uint32_t* maskD;   // [nz][ny][mws]           interior rows skewed by (y - 1) & 63, rows 0 and ny - 1 unskewed
+    uint32_t* maskU;   // [nz][gens][ny][mws]     zero on entry
+    SliceStats* stats;
+    uint32_t nx, ny, mws, gens;
+    int useDefault;
+    float defaultVal;
+    uint32_t repeat;
+    int setWeight;     // >= 0
+    uint32_t sumLanes;
+};
+
+struct HandoffC {
+    float* data;             // [16][2][kHandWC]
+    unsigned char* wcode;    // [16][2][kHandWC]  0, 1, 2 = setWeight
+    unsigned int* produced;  // [16][2]
+    unsigned int* consumed;  // [16][2]
+};
+
+// value of lane l+1 (lane 63 keeps its own): "wave_shl:1" (0x130)
+__device__ __forceinline__ uint32_t lane_from_below(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+__device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ maskD, const uint32_t* __restrict__ uOld,
+                           const uint32_t* __restrict__ uHist, uint32_t* __restrict__ uNew, float* ring, HandoffC hand, uint32_t b,
+                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, int& changed)
+{
+    using rsrc_t = __amdgpu_buffer_rsrc_t;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t y0 = 1 + kWave * b;
+    const uint32_t nrow = min((uint32_t)kWave, (ny - 1) - y0);
+    const uint32_t L = nrow - 1;
+    const bool rowValid = lane < nrow;
+    const uint32_t y = y0 + min(lane, L);
+    const uint32_t C = nx - 2;
+    const uint32_t xpEnd = C + L;
+    float* ringRow = ring + lane * kPitch;
+    const float* ringBelow = ring + min(lane + 1, (uint32_t)kWave - 1) * kPitch;
+    const float left0 = f[(size_t)y * nx];
+    const uint32_t* drow = maskD + (size_t)y * mws;
+    const uint32_t* urow = uOld + (size_t)y * mws;
+    const uint32_t* hrow = uHist ? uHist + (size_t)y * mws : nullptr;
+    uint32_t* nrowU = uNew + (size_t)y * mws;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f + (size_t)(y0 - 1) * nx, 0, (nrow + 2) * nx * 4u, 0x00020000);
+    const uint32_t kOob = 0xFFFFFFFFu;
+    // weight of border column 0 of my row: skewed column = lane
+    const float wLeft0 = ((drow[lane >> 5] >> (lane & 31)) & 1u) ? swf : 0.f;
+
+    const uint32_t crow = lane >> 4, ccol = lane & 15;
+    float stage[16];
+    auto chunk_off = [&](uint32_t c, uint32_t it, bool store) -> uint32_t {
+        const uint32_t row = 4 * it + crow;
+        const int64_t x = (int64_t)c * kCh + ccol - row;
+        const bool ok = row < nrow && (store ? (x >= 1 && x <= (int64_t)C) : (x >= 0 && x <= (int64_t)nx - 1));
+        return ok ? (uint32_t)(((row + 1) * nx + x) * 4u) : kOob;
+    };
+    auto load_chunk = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t it = 0; it < 16; ++it)
+            stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, chunk_off(c, it, false), 0, 0));
+    };
+    auto commit_chunk = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t it = 0; it < 16; ++it) ring[(4 * it + crow) * kPitch + ((c * kCh + ccol) & (kRingW - 1))] = stage[it];
+    };
+    auto flush_chunk = [&](uint32_t c) {
+        float v[16];
+#pragma unroll
+        for (uint32_t it = 0; it < 16; ++it) v[it] = ring[(4 * it + crow) * kPitch + ((c * kCh + ccol) & (kRingW - 1))];
+#pragma unroll
+        for (uint32_t it = 0; it < 16; ++it)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
+    };
+    auto load_block = [&](uint32_t rowInBuf, uint32_t k) {
+        const uint32_t col = 64 * k + lane;
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col <= nx - 1 ? (rowInBuf * nx + col) * 4u : kOob, 0, 0));
+    };
+    // weights of 64 columns of an unskewed row (row 0, the first row of the band below, row ny - 1)
+    auto load_wblock = [&](uint32_t yRow, uint32_t k) -> float {
+        const uint32_t col = min(64 * k + lane, nx - 1);
+        const uint32_t d = maskD[(size_t)yRow * mws + (col >> 5)], u = uOld[(size_t)yRow * mws + (col >> 5)];
+        return ((d >> (col & 31)) & 1u) ? swf : (float)((u >> (col & 31)) & 1u);
+    };
+
+    const uint32_t slotOut = (b % kV2Waves) * 2 + ((b / kV2Waves) & 1);
+    const uint32_t slotIn = ((b - 1) % kV2Waves) * 2 + (((b - 1) / kV2Waves) & 1);
+    float* handOut = hand.data + slotOut * kHandWC;
+    unsigned char* handOutW = hand.wcode + slotOut * kHandWC;
+    const float* handIn = hand.data + slotIn * kHandWC;
+    const unsigned char* handInW = hand.wcode + slotIn * kHandWC;
+    if (lane == 0) {
+        __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&hand.consumed[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // every 16th boundary goes through global memory (see fill2d_band): values from the flushed row, weights from the
+    // D mask and this sweep's U words of that row (skew 63), which the producing band stores at every event
+    const bool hasBelow = y0 + nrow < ny - 1;
+    const bool outGlobal = hasBelow && (b % kV2Waves) == kV2Waves - 1;
+    const bool inGlobal = b > 0 && (b % kV2Waves) == 0;
+    auto wait_above = [&](uint32_t k) {
+        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
+        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    };
+    auto load_wblock_above = [&](uint32_t k) -> float {
+        const uint32_t xs = min(64 * k + lane, nx - 1) + (kWave - 1);
+        const uint32_t d = maskD[(size_t)(y0 - 1) * mws + (xs >> 5)], u = uNew[(size_t)(y0 - 1) * mws + (xs >> 5)];
+        return ((d >> (xs & 31)) & 1u) ? swf : (float)((u >> (xs & 31)) & 1u);
+    };
+    auto take_above = [&](uint32_t k, float& fv, float& wv) {
+        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
+        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        fv = handIn[(64 * k + lane) % kHandWC];
+        const unsigned int code = handInW[(64 * k + lane) % kHandWC];
+        wv = (code == 2u) ? swf : (float)code;
+        if (lane == 0)
+            __hip_atomic_store(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    load_chunk(0);
+    commit_chunk(0);
+    load_chunk(1);
+    commit_chunk(1);
+    load_chunk(2);
+    float upCur, upWCur, upLd = 0.f, upWLd = 0.f;
+    if (b == 0) { upCur = load_block(0, 0); upWCur = load_wblock(0, 0); }
+    else if (inGlobal) { wait_above(0); upCur = load_block(0, 0); upWCur = load_wblock_above(0); }
+    else take_above(0, upCur, upWCur);
+    const uint32_t yBelow = y0 + nrow;
+    float downA = load_block(nrow + 1, 0), downB = downA, downLd = 0.f;
+    float downWA = load_wblock(yBelow, 0), downWB = downWA, downWLd = 0.f;
+    uint32_t downIssued = 0;
+    bool downLdValid = false;
+    const uint32_t wLast = mws - 1;
+    uint32_t dw = drow[0], dwN = drow[1], dwLd = drow[min(2u, wLast)];
+    uint32_t uw = urow[0], uwN = urow[1], uwLd = urow[min(2u, wLast)];
+    uint32_t hw = hrow ? hrow[0] : 0u, hwN = hrow ? hrow[1] : 0u, hwLd = hrow ? hrow[min(2u, wLast)] : 0u;
+    uint32_t ddw = lane_from_below(dw), ddwN = lane_from_below(dwN), duw = lane_from_below(uw), duwN = lane_from_below(uwN);
+    uint32_t un = 0;
+    float prevRes = 0.f, prevW = 0.f;
+    float prevRight = ringRow[1];
+
+    const uint32_t nChunks = xpEnd / kCh + 1;
+    for (uint32_t c = 0; c < nChunks; ++c) {
+        const uint32_t xpc = c * kCh;
+        if (c > 0) {
+            if (outGlobal) {
+                if (xpc > L) {  // stores of the previous event have landed: columns < 16 (c - 1) - L of the last row, values and U bits
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0 && xpc - kCh > L)
+                        __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (rowValid) nrowU[(c - 1) / 2] = un;  // the (partial) word of the chunk just finished
+            }
+            flush_chunk(c - 1);
+            commit_chunk(c + 1);
+            load_chunk(c + 2);
+            if ((c & 1) == 0) {  // x' is a multiple of 32: the finished U word goes out, every lane switches words
+                if (rowValid) nrowU[c / 2 - 1] = un;
+                un = 0;
+                const uint32_t nxt = min(c / 2 + 2, wLast);
+                dw = dwN; dwN = dwLd; dwLd = drow[nxt];
+                uw = uwN; uwN = uwLd; uwLd = urow[nxt];
+                hw = hwN; hwN = hwLd; hwLd = hrow ? hrow[nxt] : 0u;
+                ddw = ddwN; ddwN = lane_from_below(dwN);
+                duw = duwN; duwN = lane_from_below(uwN);
+            }
+            if (xpc > L && !outGlobal) {
+                if (lane == 0)
+                    __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hasBelow) {
+                    const unsigned int limit = xpc + kCh - L;
+                    while (true) {
+                        const unsigned int cns = __hip_atomic_load(&hand.consumed[slotOut], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (limit <= (cns & 0x7FFFFu) + kHandWC) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            if ((xpc & 63) == 0) {
+                if (b == 0 || inGlobal) { upCur = upLd; upWCur = upWLd; }
+                else take_above(xpc >> 6, upCur, upWCur);
+            }
+            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
+                const uint32_t k = (xpc + 2 * kCh) >> 6;
+                if (inGlobal) wait_above(k);
+                upLd = load_block(0, k);
+                upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
+            }
+            if (downLdValid) { downB = downLd; downWB = downWLd; downLdValid = false; }
+            if (xpc + 3 * kCh > L) {
+                const uint32_t k = (xpc + 3 * kCh - L) >> 6;
+                if (k > downIssued) {
+                    downLd = load_block(nrow + 1, k);
+                    downWLd = load_wblock(yBelow, k);
+                    downIssued = k;
+                    downLdValid = true;
+                }
+            }
+        }
+        const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCh - 1, xpEnd);
+        for (uint32_t xp = xp0; xp <= xp1; ++xp) {
+            if (xp > L && ((xp - L) & 63) == 0) { downA = downB; downWA = downWB; }
+            const int64_t x = (int64_t)xp - lane;
+            const bool inRange = rowValid && x >= 1 && x <= (int64_t)C;
+            const uint32_t sh = xp & 31;
+            // bit 0: this cell, bit 1: the cell to the right (own row) / the cell below (row of lane + 1)
+            const uint32_t dPair = __builtin_amdgcn_alignbit(dwN, dw, sh), uPair = __builtin_amdgcn_alignbit(uwN, uw, sh);
+            const uint32_t ddPair = __builtin_amdgcn_alignbit(ddwN, ddw, sh), duPair = __builtin_amdgcn_alignbit(duwN, duw, sh);
+            const bool cD = dPair & 1u, cU = uPair & 1u, cH = (hw >> sh) & 1u;
+            const float wr = (dPair & 2u) ? swf : ((uPair & 2u) ? 1.f : 0.f);
+            float wd = (ddPair & 2u) ? swf : ((duPair & 2u) ? 1.f : 0.f);
+            const uint32_t rp = (xp + 1) & (kRingW - 1);
+            const float right = ringRow[rp];
+            float down = ringBelow[rp];
+            const float center = prevRight;
+            float up = lane_from_above(prevRes), wu = lane_from_above(prevW);
+            const float upFirst = lane_value(upCur, (int)(xp & 63)), wuFirst = lane_value(upWCur, (int)(xp & 63));
+            if (lane == 0) { up = upFirst; wu = wuFirst; }
+            const int dIdx = (int)((xp >= L) ? ((xp - L) & 63) : 0);
+            const float downLast = lane_value(downA, dIdx), wdLast = lane_value(downWA, dIdx);
+            if (lane == L) { down = downLast; wd = wdLast; }
+            const float left = (x == 1) ? left0 : prevRes;
+            const float wl = (x == 1) ? wLeft0 : prevW;
+            const float wsum = ((wr + wl) + wd) + wu;                          // :1445, small integers: exact
+            const bool act = inRange && !cD && !cH && wsum != 0.f;             // :1443, :1446
+            float v = center + (((wr * right + wl * left) + wd * down) + wu * up);  // :1451
+            v = v / (1.f + wsum);                                              // :1452
+            const float res = act ? v : center;
+            const bool newU = cU || act;
+            if (inRange) {
+                if (act) { ringRow[xp & (kRingW - 1)] = res; changed = 1; }
+                if (lane == L) {
+                    handOut[(uint32_t)x % kHandWC] = res;
+                    handOutW[(uint32_t)x % kHandWC] = cD ? 2 : (newU ? 1 : 0);
+                }
+            }
+            un |= (newU ? 1u : 0u) << sh;
+            prevRes = res;
+            prevW = cD ? swf : (newU ? 1.f : 0.f);
+            prevRight = right;
+        }
+    }
+    flush_chunk(nChunks - 1);
+    if (rowValid) nrowU[(nChunks - 1) / 2] = un;
+    if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, C + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned long long shUndef;
+    __shared__ float shDefault;
+    float* rings = smem;
+    HandoffC hand;
+    hand.data = smem + kV2Waves * kWave * kPitch;
+    hand.wcode = reinterpret_cast<unsigned char*>(hand.data + kV2Waves * 2 * kHandWC);
+    hand.produced = reinterpret_cast<unsigned int*>(hand.wcode + kV2Waves * 2 * kHandWC);
+    hand.consumed = hand.produced + kV2Waves * 2;
+    const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
+    const size_t total = (size_t)nx * ny;
+    const size_t maskWords = (size_t)ny * mws;
+    float* f = a.field + (size_t)blockIdx.x * total;
+    uint32_t* maskD = a.maskD + (size_t)blockIdx.x * maskWords;
+    uint32_t* maskU = a.maskU + (size_t)blockIdx.x * a.gens * maskWords;
+    SliceStats* st = a.stats + blockIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+
+    unsigned long long nUndef = 0;
+    const double sum = serial_sum<kV2Threads>(f, total, a.useDefault ? 2 : 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumLanes);
+    if (threadIdx.x == 0) {
+        shUndef = nUndef;
+        const unsigned long long nDef = total - nUndef;
+        shDefault = a.useDefault ? a.defaultVal : ((nDef != 0) ? (float)(sum / (double)nDef) : 0.f);  // :1516
+        st->nUndef = nUndef;
+        st->status = 1;
+    }
+    __syncthreads();
+    nUndef = shUndef;
+    const unsigned long long nDef = total - nUndef;
+    if (nDef == 0 || nUndef == 0) return;  // :1384-1386, :1515
+    const float defaultVal = shDefault;
+    const uint32_t repeat = a.repeat;
+    const float swf = (float)a.setWeight;
+
+    // first guess and the D mask (:1408-1421): one wave per row, ballot words in the row's skew
+    for (uint32_t y = wave; y < ny; y += kV2Waves) {
+        float* row = f + (size_t)y * nx;
+        const uint32_t l = (y == 0 || y == ny - 1) ? 0u : ((y - 1) & (kWave - 1));
+        uint32_t* mrow = maskD + (size_t)y * mws;
+        for (uint32_t base = 0; base < mws * 32; base += kWave) {
+            const int64_t x = (int64_t)base + lane - l;
+            const bool in = x >= 0 && x < (int64_t)nx;
+            const float val = in ? row[x] : 0.f;
+            const bool undef = in && isnan(val);
+            const unsigned long long m = __ballot(in && !undef);
+            if (lane == 0) {
+                mrow[base / 32] = (uint32_t)m;
+                if (base / 32 + 1 < mws) mrow[base / 32 + 1] = (uint32_t)(m >> 32);
+            }
+            if (undef) row[x] = defaultVal;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
+    const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
+    float* ring = rings + wave * kWave * kPitch;
+    unsigned long long l = 0;
+    int changedInLoop = 1;
+    while (repeat > 0 && changedInLoop && l < nDef) {  // :1430 (nothing has r < repeat when repeat is 0)
+        l++;
+        if (threadIdx.x < kV2Waves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
+        __syncthreads();
+        const uint32_t* uOld = maskU + (size_t)((l - 1) % a.gens) * maskWords;
+        const uint32_t* uHist = (l > repeat) ? maskU + (size_t)((l - repeat) % a.gens) * maskWords : nullptr;
+        uint32_t* uNew = maskU + (size_t)(l % a.gens) * maskWords;
+        int mine = 0;
+        for (uint32_t b = wave; b < nBands; b += kV2Waves)
+            creep_band(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, mine);
+        changedInLoop = __syncthreads_or(mine);
+    }
+    // borders (:1464-1489): undefined border cells have r = 0 < repeat in every round, defined ones never change
+    const uint32_t* uFin = maskU + (size_t)(l % a.gens) * maskWords;
+    auto defined = [&](uint32_t y, uint32_t x) -> bool {
+        const uint32_t sk = (y == 0 || y == nym1) ? 0u : ((y - 1) & (kWave - 1));
+        return (maskD[(size_t)y * mws + ((x + sk) >> 5)] >> ((x + sk) & 31)) & 1u;
+    };
+    auto w_interior = [&](uint32_t y, uint32_t x) -> int {  // final weight of an interior cell
+        const uint32_t sk = (y - 1) & (kWave - 1);
+        if (defined(y, x)) return a.setWeight;
+        return (uFin[(size_t)y * mws + ((x + sk) >> 5)] >> ((x + sk) & 31)) & 1u;
+    };
+    for (uint32_t k = 0; k < repeat; ++k) {
+        for (uint32_t y = 1 + threadIdx.x; y < nym1; y += kV2Threads) {
+            const size_t row = (size_t)y * nx;
+            if (!defined(y, 0)) {
+                const int wn = w_interior(y, 1);
+                f[row] += f[row + 1] * wn;
+                f[row] /= (float)(1 + wn);
+            }
+            if (!defined(y, nxm1)) {
+                const int wn = w_interior(y, nx - 2);
+                f[row + nxm1] += f[row + nx - 2] * wn;
+                f[row + nxm1] /= (float)(1 + wn);
+            }
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < nx; x += kV2Threads) {
+            const size_t bo = (size_t)nym1 * nx + x;
+            const bool edge = (x == 0 || x == nxm1);  // the neighbour is a border cell of the column loop above: w = 1 if it was undefined
+            if (!defined(0, x)) {
+                const int wn = edge ? (defined(1, x) ? a.setWeight : 1) : w_interior(1, x);
+                f[x] += f[nx + x] * wn;
+                f[x] /= (float)(1 + wn);
+            }
+            if (!defined(nym1, x)) {
+                const int wn = edge ? (defined(nym1 - 1, x) ? a.setWeight : 1) : w_interior(nym1 - 1, x);
+                f[bo] += f[bo - nx] * wn;
+                f[bo] /= (float)(1 + wn);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 void collect_stats(const DeviceArray<SliceStats>& d_stats, size_t nz, size_t* h_nChanged, hipStream_t stream, const char* what)
 {
     std::vector<SliceStats> st(nz);
@@ -647,6 +1070,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         a.relaxCrit = relaxCrit;
         a.corrEff = corrEff;
         a.maxLoop = maxLoop;
+        a.sumLanes = (uint32_t)tuning("SUM_LANES", 64);
         constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandW * sizeof(float) +
                                     (size_t)kV2Waves * 4 * sizeof(unsigned int);
         static bool attrSet = false;
@@ -680,10 +1104,47 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
 {
     if (nx * ny == 0 || nz == 0) return;  // :1380
     FA_REQUIRE(nx <= 0x7FFFFFFFu && ny <= 0x7FFFFFFFu && nz <= 0x7FFFFFFFu, "creepfill: slice too large");
-    DeviceArray<signed char> w(nx * ny * nz);
-    DeviceArray<unsigned short> r(nx * ny * nz);
     DeviceArray<SliceStats> stats(nz);
     FA_HIP(hipMemsetAsync(stats.get(), 0, nz * sizeof(SliceStats), stream));
+    const char* what = useDefault ? "creepfillval2d" : "creepfill2d";
+    const size_t nBands = ny > 2 ? (ny - 2 + kWave - 1) / kWave : 0;
+    const uint32_t mws = (uint32_t)((nx + kWave + 31) / 32 + 2);
+    const size_t gens = (size_t)repeat + 1;
+    const size_t uWords = nz * gens * ny * mws;
+    // the systolic kernel keeps repeat + 1 generations of the "updated" mask; very long repeats take the counter kernel
+    if (tuning("CREEP_V2", 1) != 0 && nx >= 4 && ny >= 4 && nBands < (size_t)kMaxBands && nx < (1u << 19) &&
+        (size_t)(kWave + 2) * nx * 4 < 0xFFFFFFFFull && setWeight >= 0 && uWords * 4 <= ((size_t)8 << 30)) {
+        DeviceArray<uint32_t> maskD(nz * ny * mws), maskU(uWords);
+        FA_HIP(hipMemsetAsync(maskU.get(), 0, uWords * sizeof(uint32_t), stream));
+        CreepV2Args a{};
+        a.field = d_field;
+        a.maskD = maskD.get();
+        a.maskU = maskU.get();
+        a.stats = stats.get();
+        a.nx = (uint32_t)nx;
+        a.ny = (uint32_t)ny;
+        a.mws = mws;
+        a.gens = (uint32_t)gens;
+        a.useDefault = useDefault ? 1 : 0;
+        a.defaultVal = defaultVal;
+        a.repeat = repeat;
+        a.setWeight = (int)setWeight;
+        a.sumLanes = (uint32_t)tuning("SUM_LANES", 64);
+        constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandWC * (sizeof(float) + 1) +
+                                    (size_t)kV2Waves * 4 * sizeof(unsigned int);
+        static bool attrSet = false;
+        if (!attrSet) {
+            FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&creepfill_kernel_v2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ldsBytes));
+            attrSet = true;
+        }
+        creepfill_kernel_v2<<<dim3((uint32_t)nz), kV2Threads, ldsBytes, stream>>>(a);
+        FA_HIP(hipGetLastError());
+        collect_stats(stats, nz, h_nChanged, stream, what);
+        return;
+    }
+    DeviceArray<signed char> w(nx * ny * nz);
+    DeviceArray<unsigned short> r(nx * ny * nz);
     CreepArgs a{};
     a.field = d_field;
     a.w = w.get();
@@ -697,7 +1158,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
     a.setWeight = (signed char)setWeight;
     creepfill_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(a);
     FA_HIP(hipGetLastError());
-    collect_stats(stats, nz, h_nChanged, stream, useDefault ? "creepfillval2d" : "creepfill2d");
+    collect_stats(stats, nz, h_nChanged, stream, what);
 }
 
 }  // namespace fimex_amd

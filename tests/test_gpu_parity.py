@@ -197,7 +197,7 @@ def test_vector_rotation_90_degrees(fa):
 
 
 @pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2), (4, 4, 1), (5, 70, 1), (300, 200, 2),
-                                   (64, 66, 1), (33, 1200, 1), (1000, 131, 1)])
+                                   (64, 66, 1), (33, 1200, 1), (1000, 131, 1), (5000, 1100, 1)])
 @pytest.mark.parametrize("params", [(4.0, 1.6, 100), (0.5, 1.0, 23), (4.0, 1.9, 3), (1e-9, 1.6, 41)])
 def test_fill2d_matches_oracle(fa, shape, params):
     nx, ny, nz = shape
@@ -211,8 +211,9 @@ def test_fill2d_matches_oracle(fa, shape, params):
         assert cases.same(got[z], want), "slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
 
 
-@pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2)])
-@pytest.mark.parametrize("params", [(20, 2), (1, 1), (5, 2), (3, 0)])
+@pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2), (4, 4, 1), (5, 70, 1), (300, 200, 2),
+                                   (64, 66, 1), (33, 1200, 1), (1000, 131, 1), (5000, 1100, 1)])
+@pytest.mark.parametrize("params", [(20, 2), (1, 1), (5, 2), (3, 0), (2, 7)])
 def test_creepfill_matches_oracle(fa, shape, params):
     nx, ny, nz = shape
     repeat, weight = params
@@ -236,6 +237,31 @@ def test_fill2d_both_kernels_agree(fa, monkeypatch):
     monkeypatch.setenv("FIMEX_AMD_FILL_V2", "0")
     b, nb = fa.fill2d_host(f, 4.0, 1.6, 60)
     assert na == nb and cases.same(a, b)
+
+
+def test_creepfill_both_kernels_agree(fa, monkeypatch):
+    """Row-band kernel with mask generations against the wavefront kernel with per-cell counters; a hole that reaches the
+    lower right corner creeps one cell per sweep, so the sweep count goes well beyond repeat."""
+    f = cases.holes(2, 170, 230, seed=78)
+    f[:, 100:, 150:] = np.nan
+    f[0, :40, :50] = np.nan
+    for repeat, weight in ((3, 2), (20, 1), (300, 2)):
+        monkeypatch.setenv("FIMEX_AMD_CREEP_V2", "1")
+        a, na = fa.creepfill2d_host(f, repeat, weight)
+        monkeypatch.setenv("FIMEX_AMD_CREEP_V2", "0")
+        b, nb = fa.creepfill2d_host(f, repeat, weight)
+        assert na == nb and cases.same(a, b), cases.describe_mismatch(a, b)
+    want, wn, rc = oracle.creepfill2d(f[0], 3, 2)
+    monkeypatch.setenv("FIMEX_AMD_CREEP_V2", "1")
+    assert cases.same(fa.creepfill2d_host(f[:1], 3, 2)[0][0], want)
+
+
+def test_creepfill_negative_weight_takes_the_counter_kernel(fa):
+    """a negative setWeight wraps in the reference's size_t sum (interpolation.c:1445); only the counter kernel mirrors that."""
+    f = cases.holes(1, 40, 50, seed=5)
+    got, n = fa.creepfill2d_host(f, 2, -1)
+    want, wn, rc = oracle.creepfill2d(f[0], 2, -1)
+    assert cases.same(got[0], want), cases.describe_mismatch(got[0], want)
 
 
 def test_fills_leave_complete_and_empty_slices_alone(fa):

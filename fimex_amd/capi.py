@@ -76,6 +76,7 @@ SYMBOLS = {
     "fimex_amd_nan2bad_device": (ctypes.c_int, [_V, _Z, ctypes.c_float, _V]),
     "fimex_amd_points2position_device": (ctypes.c_int, [_V, _Z, _D, ctypes.c_int, ctypes.c_int, _V]),
     "fimex_amd_points2position_host": (ctypes.c_int, [_D, _Z, _D, ctypes.c_int, ctypes.c_int]),
+    "fimex_amd_scan_sum_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _ZP, _V]),
 }
 
 _lib = None
@@ -289,6 +290,14 @@ def bad2nan_device(d_data, n, bad, stream=0):
 
 def nan2bad_device(d_data, n, bad, stream=0):
     _check(load().fimex_amd_nan2bad_device(d_data, n, bad, stream))
+
+
+def scan_sum_device(d_values, n, mode=0, average=0.0, algo=1, stream=0):
+    """(sum, nUndefined) of the fills' scan-order double accumulation over n device floats."""
+    out = ctypes.c_double(0.0)
+    und = ctypes.c_size_t(0)
+    _check(load().fimex_amd_scan_sum_device(d_values, n, mode, average, algo, ctypes.byref(out), ctypes.byref(und), stream))
+    return out.value, und.value
 
 
 def points2position_host(points, axis, axis_type=PROJ_AXIS):

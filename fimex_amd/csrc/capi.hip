@@ -494,4 +494,13 @@ int fimex_amd_points2position_host(double* points, size_t n, const double* axis,
     });
 }
 
+int fimex_amd_scan_sum_device(const float* d_values, size_t n, int mode, double average, int algo, double* sum, size_t* nUndefined, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(sum != nullptr && (d_values != nullptr || n == 0), "NULL argument");
+        (void)current_device_checked();
+        run_scan_sum(d_values, n, mode, average, algo, sum, nUndefined, as_stream(stream));
+    });
+}
+
 }  // extern "C"

@@ -47,7 +47,7 @@ __device__ __forceinline__ double sum_addend(float v, int mode, double average, 
 
 template <int BLOCK = kFillBlock>
 __device__ double serial_sum(const float* __restrict__ f, size_t total, int mode, double average, double* buf,
-                             unsigned long long* nUndefOut, unsigned chainLanes = kWave)
+                             unsigned long long* nUndefOut)
 {
     __shared__ unsigned long long shCount;
     constexpr int kProducers = BLOCK - kWave;
@@ -61,7 +61,7 @@ __device__ double serial_sum(const float* __restrict__ f, size_t total, int mode
     __syncthreads();
     for (size_t t = 0; t < nTiles; ++t) {
         if (threadIdx.x < kWave) {
-            if (mode != 2 && threadIdx.x < chainLanes) {
+            if (mode != 2) {
                 const double2* b2 = reinterpret_cast<const double2*>(buf + (t & 1) * kSumTile);
                 double2 q0 = b2[0], q1 = b2[1], q2 = b2[2], q3 = b2[3];
 #pragma unroll 2
@@ -90,6 +90,196 @@ __device__ double serial_sum(const float* __restrict__ f, size_t total, int mode
     return sum;  // valid in wave 0
 }
 
+// ---- the same sums without walking the chain: "binade-parallel" evaluation, bit for bit the sequential result.
+//
+// While the running sum S stays inside one binade [2^e, 2^(e+1)), it is a multiple of u = 2^(e-52) and every
+// S <- fl(S + a) rounds the exact value to a multiple of u, so fl(S + a) = S + rn_u(a) whenever a is not exactly halfway
+// between two multiples of u (rn_u: round to the nearest multiple).  The rounded addends k = rn_u(a) / u are integers and
+// integer sums are associative: a chunk of 512 elements contributes I = sum k, in any order, PROVIDED S provably stays
+// inside the binade for all 512 partial sums.  With A = sum |k| and m = |S| / u (an integer in [2^52, 2^53)) that is
+// guaranteed by  m - A >= 2^52 + 1  and  m + A <= 2^53 - 1  (the +-1 keeps the exact, unrounded partial sums inside as
+// well), and A < 2^50 keeps all integer arithmetic exact in doubles.  A chunk that fails any test -- a tie, a binade
+// crossing, S = 0, non-finite values -- is re-evaluated at the binade S has by then, or walked element by element.
+// Per super-block of 16 chunks: every wave evaluates its chunk at the binade S had after the previous super-block,
+// then wave 0 strings the 16 results together (lanes = chunks, prefix over I) and repairs what failed.
+constexpr int kSumE = 8;                  // consecutive elements per lane
+constexpr int kChunk = kWave * kSumE;     // elements per wave and super-block
+constexpr int kNoBinade = 0x7fffffff;
+
+__device__ __forceinline__ double pow2d(int e) { return __longlong_as_double((long long)(e + 1023) << 52); }  // |e| < 1000
+__device__ __forceinline__ int exponent_of(double s) { return (int)((__double_as_longlong(s) >> 52) & 0x7FF) - 1023; }
+__device__ __forceinline__ bool binade_usable(double s, int e) { return s != 0.0 && e > -900 && e < 900; }  // excludes inf, NaN, subnormals
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double lane_value_d(double v, int idx)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, idx), hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), idx);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+struct ChunkSum {
+    double I, A;
+    bool ok;
+};
+
+__device__ __forceinline__ void chunk_addends(const float* __restrict__ f, size_t base, size_t total, int mode, double average,
+                                              double (&a)[kSumE], unsigned int* nUndef)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int j = 0; j < kSumE; ++j) {
+        const size_t i = base + (size_t)lane * kSumE + j;
+        const bool in = i < total;
+        const float v = in ? f[i] : 0.f;
+        const bool undef = isnan(v);
+        if (nUndef) *nUndef += undef;
+        a[j] = (undef || !in) ? 0.0 : (mode == 0 ? (double)v : fabs((double)v - average));
+    }
+}
+
+// one wave, 512 consecutive elements from `base`: integer image of the addends at binade e
+__device__ ChunkSum chunk_eval(const float* __restrict__ f, size_t base, size_t total, int mode, double average, int e, unsigned int* nUndef)
+{
+    double a[kSumE];
+    chunk_addends(f, base, total, mode, average, a, nUndef);
+    const double scale = pow2d(52 - e);
+    double sI = 0, sA = 0;
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j < kSumE; ++j) {
+        const double t = a[j] * scale;  // exact: a power of two
+        const double k = rint(t);
+        tie |= (fabs(t - k) == 0.5);
+        sI += k;
+        sA += fabs(k);
+    }
+    ChunkSum r;
+    r.I = wave_sum_d(sI);
+    r.A = wave_sum_d(sA);
+    r.ok = !__any(tie) && r.A < 0x1p50;  // false for inf and NaN as well
+    return r;
+}
+
+// one wave, the same 512 elements one after the other on the running sum
+__device__ double chunk_chain(const float* __restrict__ f, size_t base, size_t total, int mode, double average, double S)
+{
+    double a[kSumE];
+    chunk_addends(f, base, total, mode, average, a, nullptr);
+    for (int l = 0; l < kWave; ++l) {
+#pragma unroll
+        for (int j = 0; j < kSumE; ++j) S += lane_value_d(a[j], l);
+    }
+    return S;
+}
+
+template <int BLOCK = kFillBlock>
+__device__ double binade_sum(const float* __restrict__ f, size_t total, int mode, double average, unsigned long long* nUndefOut)
+{
+    constexpr int kWaves = BLOCK / kWave;
+    static_assert(kWaves <= 16, "lanes 0..15 of wave 0 stand for the chunks of a super-block");
+    constexpr size_t kSuper = (size_t)kWaves * kChunk;
+    __shared__ double shI[kWaves], shA[kWaves];
+    __shared__ int shOk[kWaves];
+    __shared__ int shE;
+    __shared__ unsigned long long shCount;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    unsigned int myUndef = 0;
+    double S = 0;  // wave 0
+    if (threadIdx.x == 0) { shE = kNoBinade; shCount = 0; }
+    __syncthreads();
+    if (mode == 2) {
+        for (size_t i = threadIdx.x; i < total; i += BLOCK) myUndef += isnan(f[i]);
+    } else {
+        for (size_t sb = 0; sb < total; sb += kSuper) {
+            const int e = shE;
+            ChunkSum cs = chunk_eval(f, sb + (size_t)wave * kChunk, total, mode, average, e == kNoBinade ? 0 : e, &myUndef);
+            if (lane == 0) { shI[wave] = cs.I; shA[wave] = cs.A; shOk[wave] = (cs.ok && e != kNoBinade) ? 1 : 0; }
+            __syncthreads();
+            if (wave == 0) {
+                const int nCh = (int)(((total - sb < kSuper ? total - sb : kSuper) + kChunk - 1) / kChunk);
+                const double I = lane < (uint32_t)kWaves ? shI[lane] : 0.0, A = lane < (uint32_t)kWaves ? shA[lane] : 0.0;
+                const bool ok = lane < (uint32_t)kWaves && shOk[lane] != 0;
+                int w0 = 0;
+                while (w0 < nCh) {
+                    int eS = exponent_of(S);
+                    if (binade_usable(S, eS) && eS == e) {
+                        const double n = fabs(S) * pow2d(52 - eS), sg = S < 0 ? -1.0 : 1.0;
+                        const double x = ((int)lane >= w0 && (int)lane < nCh) ? sg * I : 0.0;
+                        double incl = x;
+                        for (int o = 1; o < 16; o <<= 1) {
+                            const double yv = __shfl_up(incl, o);
+                            if ((int)lane >= o) incl += yv;
+                        }
+                        const double m = n + (incl - x);  // |S| / u before chunk `lane`, if all chunks from w0 on can be taken
+                        const bool good = ok && (m - A >= 0x1p52 + 1.0) && (m + A <= 0x1p53 - 1.0);
+                        const unsigned long long bad = __ballot((int)lane >= w0 && (int)lane < nCh && !good);
+                        const int wf = bad ? (int)__ffsll((long long)bad) - 1 : nCh;
+                        if (wf > w0) S = sg * ((n + lane_value_d(incl, wf - 1)) * pow2d(eS - 52));
+                        w0 = wf;
+                        if (w0 == nCh) break;
+                    }
+                    // chunk w0 on its own: at the binade S is in now, else element by element
+                    const size_t cb = sb + (size_t)w0 * kChunk;
+                    eS = exponent_of(S);
+                    bool done = false;
+                    if (binade_usable(S, eS)) {
+                        const ChunkSum one = chunk_eval(f, cb, total, mode, average, eS, nullptr);
+                        const double n = fabs(S) * pow2d(52 - eS), sg = S < 0 ? -1.0 : 1.0;
+                        if (one.ok && (n - one.A >= 0x1p52 + 1.0) && (n + one.A <= 0x1p53 - 1.0)) {
+                            S = sg * ((n + sg * one.I) * pow2d(eS - 52));
+                            done = true;
+                        }
+                    }
+                    if (!done) S = chunk_chain(f, cb, total, mode, average, S);
+                    ++w0;
+                }
+                if (lane == 0) {
+                    const int eS = exponent_of(S);
+                    shE = binade_usable(S, eS) ? eS : kNoBinade;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (nUndefOut) {
+        if (myUndef) atomicAdd(&shCount, (unsigned long long)myUndef);
+        __syncthreads();
+        *nUndefOut = shCount;
+        __syncthreads();
+    }
+    return S;  // valid in wave 0
+}
+
+// algo 0: the chain (serial_sum), 1: binade-parallel
+template <int BLOCK = kFillBlock>
+__device__ double scan_order_sum(const float* __restrict__ f, size_t total, int mode, double average, double* buf,
+                                 unsigned long long* nUndefOut, int algo)
+{
+    if (algo == 0) return serial_sum<BLOCK>(f, total, mode, average, buf, nUndefOut);
+    return binade_sum<BLOCK>(f, total, mode, average, nUndefOut);
+}
+
+struct ScanSumArgs {
+    const float* values;
+    size_t n;
+    int mode, algo;
+    double average;
+    double* sum;
+    unsigned long long* nUndef;
+};
+
+__global__ void __launch_bounds__(kFillBlock) scan_sum_kernel(ScanSumArgs a)
+{
+    __shared__ __align__(16) double lds[2 * kSumTile];
+    unsigned long long nUndef = 0;
+    const double s = scan_order_sum(a.values, a.n, a.mode, a.average, lds, &nUndef, a.algo);
+    if (threadIdx.x == 0) { *a.sum = s; *a.nUndef = nUndef; }
+}
+
 // ---------------------------------------------------------------------------------- fill2d
 struct Fill2dArgs {
     float* field;
@@ -98,6 +288,7 @@ struct Fill2dArgs {
     uint32_t nx, ny;
     float relaxCrit, corrEff;
     unsigned long long maxLoop;
+    int sumAlgo;
 };
 
 __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
@@ -112,7 +303,7 @@ __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
     SliceStats* st = a.stats + blockIdx.x;
 
     unsigned long long nUndef = 0;
-    const double sum = serial_sum(f, total, 0, 0., lds, &nUndef);
+    const double sum = scan_order_sum(f, total, 0, 0., lds, &nUndef, a.sumAlgo);
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -127,7 +318,7 @@ __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
     if (nx < 2 || ny < 2) { if (threadIdx.x == 0) st->status = -1; return; }  // the reference reads out of bounds here
     const double average = shAverage;
 
-    const double dev = serial_sum(f, total, 1, average, lds, nullptr);
+    const double dev = scan_order_sum(f, total, 1, average, lds, nullptr, a.sumAlgo);
     if (threadIdx.x == 0) shCrit = (double)a.relaxCrit * (dev / (double)nDef);  // :1300-1302
     __syncthreads();
     const double crit = shCrit;
@@ -218,7 +409,7 @@ struct Fill2dV2Args {
     uint32_t nx, ny, mws;
     float relaxCrit, corrEff;
     unsigned long long maxLoop;
-    uint32_t sumLanes;
+    int sumAlgo;
 };
 
 // value of lane l-1 (lane 0 keeps its own): one DPP move, "wave_shr:1" (0x138), no LDS round trip
@@ -448,7 +639,7 @@ __global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 
     unsigned long long nUndef = 0;
-    const double sum = serial_sum<kV2Threads>(f, total, 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumLanes);
+    const double sum = scan_order_sum<kV2Threads>(f, total, 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumAlgo);
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -461,7 +652,7 @@ __global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
     const unsigned long long nDef = total - nUndef;
     if (nDef == 0 || nUndef == 0) return;
     const double average = shAverage;
-    const double dev = serial_sum<kV2Threads>(f, total, 1, average, reinterpret_cast<double*>(smem), nullptr, a.sumLanes);
+    const double dev = scan_order_sum<kV2Threads>(f, total, 1, average, reinterpret_cast<double*>(smem), nullptr, a.sumAlgo);
     if (threadIdx.x == 0) shCrit = (double)a.relaxCrit * (dev / (double)nDef);
     __syncthreads();
     const double crit = shCrit;
@@ -542,6 +733,7 @@ struct CreepArgs {
     float defaultVal;
     unsigned short repeat;
     signed char setWeight;
+    int sumAlgo;
 };
 
 __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
@@ -558,7 +750,7 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
     SliceStats* st = a.stats + blockIdx.x;
 
     unsigned long long nUndef = 0;
-    const double sum = serial_sum(f, total, a.useDefault ? 2 : 0, 0., lds, &nUndef);  // a default value needs no average
+    const double sum = scan_order_sum(f, total, a.useDefault ? 2 : 0, 0., lds, &nUndef, a.sumAlgo);  // a default value needs no average
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -670,7 +862,7 @@ struct CreepV2Args {
     float defaultVal;
     uint32_t repeat;
     int setWeight;     // >= 0
-    uint32_t sumLanes;
+    int sumAlgo;
 };
 
 struct HandoffC {
@@ -932,7 +1124,7 @@ __global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 
     unsigned long long nUndef = 0;
-    const double sum = serial_sum<kV2Threads>(f, total, a.useDefault ? 2 : 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumLanes);
+    const double sum = scan_order_sum<kV2Threads>(f, total, a.useDefault ? 2 : 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumAlgo);
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -1070,7 +1262,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         a.relaxCrit = relaxCrit;
         a.corrEff = corrEff;
         a.maxLoop = maxLoop;
-        a.sumLanes = (uint32_t)tuning("SUM_LANES", 64);
+        a.sumAlgo = tuning("SUM_ALGO", 1);
         constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandW * sizeof(float) +
                                     (size_t)kV2Waves * 4 * sizeof(unsigned int);
         static bool attrSet = false;
@@ -1094,6 +1286,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
     a.relaxCrit = relaxCrit;
     a.corrEff = corrEff;
     a.maxLoop = maxLoop;
+    a.sumAlgo = tuning("SUM_ALGO", 1);
     fill2d_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(a);
     FA_HIP(hipGetLastError());
     collect_stats(stats, nz, h_nChanged, stream, "fill2d");
@@ -1129,7 +1322,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         a.defaultVal = defaultVal;
         a.repeat = repeat;
         a.setWeight = (int)setWeight;
-        a.sumLanes = (uint32_t)tuning("SUM_LANES", 64);
+        a.sumAlgo = tuning("SUM_ALGO", 1);
         constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandWC * (sizeof(float) + 1) +
                                     (size_t)kV2Waves * 4 * sizeof(unsigned int);
         static bool attrSet = false;
@@ -1156,9 +1349,25 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
     a.defaultVal = defaultVal;
     a.repeat = repeat;
     a.setWeight = (signed char)setWeight;
+    a.sumAlgo = tuning("SUM_ALGO", 1);
     creepfill_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(a);
     FA_HIP(hipGetLastError());
     collect_stats(stats, nz, h_nChanged, stream, what);
+}
+
+void run_scan_sum(const float* d_values, size_t n, int mode, double average, int algo, double* h_sum, size_t* h_nUndefined, hipStream_t stream)
+{
+    FA_REQUIRE(mode >= 0 && mode <= 2 && (algo == 0 || algo == 1), "scan_sum: mode 0..2, algo 0..1");
+    DeviceArray<double> d_sum(1);
+    DeviceArray<unsigned long long> d_undef(1);
+    ScanSumArgs a{d_values, n, mode, algo, average, d_sum.get(), d_undef.get()};
+    scan_sum_kernel<<<1, kFillBlock, 0, stream>>>(a);
+    FA_HIP(hipGetLastError());
+    unsigned long long u = 0;
+    FA_HIP(hipMemcpyAsync(h_sum, d_sum.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipMemcpyAsync(&u, d_undef.get(), sizeof(u), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    if (h_nUndefined) *h_nUndefined = (size_t)u;
 }
 
 }  // namespace fimex_amd

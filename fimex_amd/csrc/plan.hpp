@@ -102,6 +102,9 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
 void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefault, float defaultVal,
                    unsigned short repeat, char setWeight, size_t* h_nChanged, hipStream_t stream);
 
+void run_scan_sum(const float* d_values, size_t n, int mode, double average, int algo, double* h_sum, size_t* h_nUndefined,
+                  hipStream_t stream);
+
 // tuning knobs read once from the environment (FIMEX_AMD_<NAME>), for bench sweeps
 int tuning(const char* name, int fallback);
 

@@ -222,6 +222,14 @@ int fimex_amd_points2position_device(double* d_points, size_t n, const double* a
 /** Same on n host doubles (copied to the GPU and back). */
 int fimex_amd_points2position_host(double* points, size_t n, const double* axis, int num, int axis_type);
 
+/* ------------------------------------------------------------- diagnostics */
+/** The scan-order double sums the fills start with (src/interpolation.c:1256-1264 sum of the defined values, mode 0;
+ *  :1288-1299 sum of |v - average|, mode 1; mode 2 only counts), on n device floats: exactly the value the reference's
+ *  sequential loop accumulates.  algo 0 walks the additions one by one, algo 1 evaluates them binade-parallel (the
+ *  fills' default); both must agree bit for bit -- this entry exists so that tests can check that directly. */
+int fimex_amd_scan_sum_device(const float* d_values, size_t n, int mode, double average, int algo,
+                              double* sum, size_t* nUndefined, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -264,6 +264,77 @@ def test_creepfill_negative_weight_takes_the_counter_kernel(fa):
     assert cases.same(got[0], want), cases.describe_mismatch(got[0], want)
 
 
+def _seq_sum(d):
+    """double sum = 0; for (...) sum += d[i];  -- cumsum adds strictly one after the other"""
+    return np.cumsum(np.concatenate([[0.0], d]))[-1]
+
+
+def _scan_field(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "kelvin":
+        x = rng.normal(280, 12, n)
+    elif kind == "wind":
+        x = rng.normal(0, 8, n) * np.sin(np.arange(n) * 1e-3)
+    elif kind == "tiny_and_huge":
+        x = rng.normal(0, 1, n) * 10.0 ** rng.integers(-30, 30, n)
+    elif kind == "alternating":
+        x = np.where(np.arange(n) % 2 == 0, 1.0, -1.0) * rng.uniform(0.5, 2.0, n) * 1e6
+    elif kind == "precip":
+        x = np.where(rng.random(n) < 0.7, 0.0, rng.gamma(0.5, 2.0, n) * 1e-3)
+    elif kind == "ties":  # small integers and halves: exact ties against large binades are common
+        x = rng.integers(-4, 5, n) * 0.5 + np.where(np.arange(n) == 5, 2.0 ** 40, 0.0)
+    elif kind == "cancel":  # the running sum returns to zero and changes sign again and again
+        b = rng.normal(0, 100, n // 2 + 1)
+        x = np.stack([b, -b], axis=1).ravel()[:n]
+    else:
+        raise ValueError(kind)
+    x = x.astype(np.float32)
+    x[rng.random(n) < 0.03] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("kind", ["kelvin", "wind", "tiny_and_huge", "alternating", "precip", "ties", "cancel"])
+@pytest.mark.parametrize("n", [1, 511, 513, 8191, 8193, 300007])
+def test_scan_order_sums_equal_the_sequential_loop(fa, kind, n):
+    """Both evaluations of the fills' double sums (chain, binade-parallel) against numpy's strictly sequential cumsum,
+    which performs the additions of interpolation.c:1256-1264 / 1288-1299 one after the other."""
+    import torch
+    x = _scan_field(kind, n, seed=n % 97 + len(kind))
+    ok = ~np.isnan(x)
+    d = x[ok].astype(np.float64)
+    want0 = _seq_sum(d)
+    avg = want0 / d.size if d.size else 0.0
+    want1 = _seq_sum(np.abs(d - avg))
+    t = torch.from_numpy(x).cuda()
+    for algo in (0, 1):
+        s0, u0 = fa.scan_sum_device(t.data_ptr(), n, 0, 0.0, algo)
+        s1, u1 = fa.scan_sum_device(t.data_ptr(), n, 1, avg, algo)
+        s2, u2 = fa.scan_sum_device(t.data_ptr(), n, 2, 0.0, algo)
+        assert u0 == u1 == u2 == n - d.size
+        assert np.float64(s0).tobytes() == np.float64(want0).tobytes(), (algo, s0, want0)
+        assert np.float64(s1).tobytes() == np.float64(want1).tobytes(), (algo, s1, want1)
+
+
+def test_scan_order_sums_full_slice_and_nonfinite(fa):
+    import torch
+    for kind, n in (("kelvin", 9_000_000), ("wind", 9_000_000), ("cancel", 2_000_001)):
+        x = _scan_field(kind, n, seed=3)
+        d = x[~np.isnan(x)].astype(np.float64)
+        want0 = _seq_sum(d)
+        avg = want0 / d.size
+        want1 = _seq_sum(np.abs(d - avg))
+        t = torch.from_numpy(x).cuda()
+        assert np.float64(fa.scan_sum_device(t.data_ptr(), n, 0, 0.0, 1)[0]).tobytes() == np.float64(want0).tobytes()
+        assert np.float64(fa.scan_sum_device(t.data_ptr(), n, 1, avg, 1)[0]).tobytes() == np.float64(want1).tobytes()
+    x = _scan_field("kelvin", 50000, seed=9)
+    x[20000] = np.inf
+    t = torch.from_numpy(x).cuda()
+    assert fa.scan_sum_device(t.data_ptr(), x.size, 0, 0.0, 1)[0] == np.inf
+    x[30000] = -np.inf
+    t = torch.from_numpy(x).cuda()
+    assert np.isnan(fa.scan_sum_device(t.data_ptr(), x.size, 0, 0.0, 1)[0])
+
+
 def test_fills_leave_complete_and_empty_slices_alone(fa):
     full = cases.field(1, 20, 30, seed=1, nan_frac=0, extremes=False)
     empty = np.full((1, 20, 30), np.nan, np.float32)

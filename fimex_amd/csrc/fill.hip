@@ -95,25 +95,20 @@ __device__ double serial_sum(const float* __restrict__ f, size_t total, int mode
 // While the running sum S stays inside one binade [2^e, 2^(e+1)), it is a multiple of u = 2^(e-52) and every
 // S <- fl(S + a) rounds the exact value to a multiple of u, so fl(S + a) = S + rn_u(a) whenever a is not exactly halfway
 // between two multiples of u (rn_u: round to the nearest multiple).  The rounded addends k = rn_u(a) / u are integers and
-// integer sums are associative: a chunk of 512 elements contributes I = sum k, in any order, PROVIDED S provably stays
-// inside the binade for all 512 partial sums.  With A = sum |k| and m = |S| / u (an integer in [2^52, 2^53)) that is
+// integer sums are associative: a chunk of 1024 elements contributes I = sum k, in any order, PROVIDED S provably stays
+// inside the binade for all 1024 partial sums.  With A = sum |k| and m = |S| / u (an integer in [2^52, 2^53)) that is
 // guaranteed by  m - A >= 2^52 + 1  and  m + A <= 2^53 - 1  (the +-1 keeps the exact, unrounded partial sums inside as
 // well), and A < 2^50 keeps all integer arithmetic exact in doubles.  A chunk that fails any test -- a tie, a binade
 // crossing, S = 0, non-finite values -- is re-evaluated at the binade S has by then, or walked element by element.
 // Per super-block of 16 chunks: every wave evaluates its chunk at the binade S had after the previous super-block,
 // then wave 0 strings the 16 results together (lanes = chunks, prefix over I) and repairs what failed.
-constexpr int kSumE = 8;                  // consecutive elements per lane
+constexpr int kSumE = 16;                 // elements per lane
 constexpr int kChunk = kWave * kSumE;     // elements per wave and super-block
 constexpr int kNoBinade = 0x7fffffff;
 
 __device__ __forceinline__ double pow2d(int e) { return __longlong_as_double((long long)(e + 1023) << 52); }  // |e| < 1000
 __device__ __forceinline__ int exponent_of(double s) { return (int)((__double_as_longlong(s) >> 52) & 0x7FF) - 1023; }
 __device__ __forceinline__ bool binade_usable(double s, int e) { return s != 0.0 && e > -900 && e < 900; }  // excludes inf, NaN, subnormals
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 __device__ __forceinline__ double lane_value_d(double v, int idx)
 {
     const long long b = __double_as_longlong(v);
@@ -121,31 +116,67 @@ __device__ __forceinline__ double lane_value_d(double v, int idx)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// v of the lane CTRL names (DPP: 0x110 + n = n lanes up within the row of 16, 0x142 / 0x143 = last lane of the previous
+// row / of the first half), 0.0 where there is none or the row is masked out: cross-lane adds without an LDS round trip
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// inclusive prefix sum within each row of 16 lanes
+__device__ __forceinline__ double row_scan_d(double v)
+{
+    v += dpp_d<0x111>(v);
+    v += dpp_d<0x112>(v);
+    v += dpp_d<0x114>(v);
+    v += dpp_d<0x118>(v);
+    return v;
+}
+// sum over the wave, in every lane (exact integers: the order does not matter)
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v = row_scan_d(v);           // lane 15 of each row: the row's sum
+    v += dpp_d<0x142, 0xa>(v);   // rows 1 and 3 += row before
+    v += dpp_d<0x143, 0xc>(v);   // rows 2 and 3 += first half
+    return lane_value_d(v, kWave - 1);
+}
+
 struct ChunkSum {
     double I, A;
     bool ok;
 };
 
-__device__ __forceinline__ void chunk_addends(const float* __restrict__ f, size_t base, size_t total, int mode, double average,
+__device__ __forceinline__ void chunk_load(const float* __restrict__ f, size_t base, size_t total, float (&v)[kSumE])
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int j = 0; j < kSumE; ++j) {  // element j * 64 + lane of the chunk: coalesced; the integer sums do not care about order
+        const size_t i = base + (size_t)j * kWave + lane;
+        v[j] = (i < total) ? f[i] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void chunk_addends(const float (&v)[kSumE], size_t base, size_t total, int mode, double average,
                                               double (&a)[kSumE], unsigned int* nUndef)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int j = 0; j < kSumE; ++j) {
-        const size_t i = base + (size_t)lane * kSumE + j;
-        const bool in = i < total;
-        const float v = in ? f[i] : 0.f;
-        const bool undef = isnan(v);
+        const bool in = base + (size_t)j * kWave + lane < total;
+        const bool undef = isnan(v[j]);
         if (nUndef) *nUndef += undef;
-        a[j] = (undef || !in) ? 0.0 : (mode == 0 ? (double)v : fabs((double)v - average));
+        a[j] = (undef || !in) ? 0.0 : (mode == 0 ? (double)v[j] : fabs((double)v[j] - average));
     }
 }
 
-// one wave, 512 consecutive elements from `base`: integer image of the addends at binade e
-__device__ ChunkSum chunk_eval(const float* __restrict__ f, size_t base, size_t total, int mode, double average, int e, unsigned int* nUndef)
+// one wave, 1024 consecutive elements from `base` (already in v): integer image of the addends at binade e
+__device__ ChunkSum chunk_eval(const float (&v)[kSumE], size_t base, size_t total, int mode, double average, int e, unsigned int* nUndef)
 {
     double a[kSumE];
-    chunk_addends(f, base, total, mode, average, a, nUndef);
+    chunk_addends(v, base, total, mode, average, a, nUndef);
     const double scale = pow2d(52 - e);
     double sI = 0, sA = 0;
     bool tie = false;
@@ -164,14 +195,16 @@ __device__ ChunkSum chunk_eval(const float* __restrict__ f, size_t base, size_t 
     return r;
 }
 
-// one wave, the same 512 elements one after the other on the running sum
+// one wave, the same 1024 elements one after the other on the running sum
 __device__ double chunk_chain(const float* __restrict__ f, size_t base, size_t total, int mode, double average, double S)
 {
+    float v[kSumE];
     double a[kSumE];
-    chunk_addends(f, base, total, mode, average, a, nullptr);
-    for (int l = 0; l < kWave; ++l) {
+    chunk_load(f, base, total, v);
+    chunk_addends(v, base, total, mode, average, a, nullptr);
 #pragma unroll
-        for (int j = 0; j < kSumE; ++j) S += lane_value_d(a[j], l);
+    for (int j = 0; j < kSumE; ++j) {
+        for (int l = 0; l < kWave; ++l) S += lane_value_d(a[j], l);
     }
     return S;
 }
@@ -194,9 +227,15 @@ __device__ double binade_sum(const float* __restrict__ f, size_t total, int mode
     if (mode == 2) {
         for (size_t i = threadIdx.x; i < total; i += BLOCK) myUndef += isnan(f[i]);
     } else {
+        float vNext[kSumE];
+        chunk_load(f, (size_t)wave * kChunk, total, vNext);
         for (size_t sb = 0; sb < total; sb += kSuper) {
             const int e = shE;
-            ChunkSum cs = chunk_eval(f, sb + (size_t)wave * kChunk, total, mode, average, e == kNoBinade ? 0 : e, &myUndef);
+            float vCur[kSumE];
+#pragma unroll
+            for (int j = 0; j < kSumE; ++j) vCur[j] = vNext[j];
+            chunk_load(f, sb + kSuper + (size_t)wave * kChunk, total, vNext);  // the next super-block, while this one is worked on
+            ChunkSum cs = chunk_eval(vCur, sb + (size_t)wave * kChunk, total, mode, average, e == kNoBinade ? 0 : e, &myUndef);
             if (lane == 0) { shI[wave] = cs.I; shA[wave] = cs.A; shOk[wave] = (cs.ok && e != kNoBinade) ? 1 : 0; }
             __syncthreads();
             if (wave == 0) {
@@ -209,11 +248,7 @@ __device__ double binade_sum(const float* __restrict__ f, size_t total, int mode
                     if (binade_usable(S, eS) && eS == e) {
                         const double n = fabs(S) * pow2d(52 - eS), sg = S < 0 ? -1.0 : 1.0;
                         const double x = ((int)lane >= w0 && (int)lane < nCh) ? sg * I : 0.0;
-                        double incl = x;
-                        for (int o = 1; o < 16; o <<= 1) {
-                            const double yv = __shfl_up(incl, o);
-                            if ((int)lane >= o) incl += yv;
-                        }
+                        const double incl = row_scan_d(x);
                         const double m = n + (incl - x);  // |S| / u before chunk `lane`, if all chunks from w0 on can be taken
                         const bool good = ok && (m - A >= 0x1p52 + 1.0) && (m + A <= 0x1p53 - 1.0);
                         const unsigned long long bad = __ballot((int)lane >= w0 && (int)lane < nCh && !good);
@@ -227,7 +262,9 @@ __device__ double binade_sum(const float* __restrict__ f, size_t total, int mode
                     eS = exponent_of(S);
                     bool done = false;
                     if (binade_usable(S, eS)) {
-                        const ChunkSum one = chunk_eval(f, cb, total, mode, average, eS, nullptr);
+                        float vOne[kSumE];
+                        chunk_load(f, cb, total, vOne);
+                        const ChunkSum one = chunk_eval(vOne, cb, total, mode, average, eS, nullptr);
                         const double n = fabs(S) * pow2d(52 - eS), sg = S < 0 ? -1.0 : 1.0;
                         if (one.ok && (n - one.A >= 0x1p52 + 1.0) && (n + one.A <= 0x1p53 - 1.0)) {
                             S = sg * ((n + sg * one.I) * pow2d(eS - 52));

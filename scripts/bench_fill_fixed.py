@@ -20,3 +20,12 @@ for lanes in sys.argv[1:] or ["0", "1"]:
         t0 = time.perf_counter(); fa.fill2d_device(d.data_ptr(), nx, ny, 4, 1e-12, 1.6, 1, st); torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     print(json.dumps({"sum_algo": int(lanes), "ms_one_sweep_call": best * 1e3}), flush=True)
+x = d0[0].contiguous().view(-1)
+for algo in (0, 1):
+    for mode, avg in ((0, 0.0), (1, 280.0)):
+        best = 1e9
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            fa.scan_sum_device(x.data_ptr(), x.numel(), mode, avg, algo, st)
+            best = min(best, time.perf_counter() - t0)
+        print(json.dumps({"scan_sum_algo": algo, "mode": mode, "n": x.numel(), "ms": best * 1e3}), flush=True)

@@ -29,7 +29,8 @@ class PlanInfo(ctypes.Structure):
     _fields_ = [("funcType", ctypes.c_int), ("device", ctypes.c_int),
                 ("inX", ctypes.c_size_t), ("inY", ctypes.c_size_t), ("outX", ctypes.c_size_t), ("outY", ctypes.c_size_t),
                 ("planBytes", ctypes.c_size_t), ("undefinedCells", ctypes.c_size_t), ("borderCells", ctypes.c_size_t),
-                ("maxBucket", ctypes.c_size_t), ("mappedSourceCells", ctypes.c_size_t)]
+                ("maxBucket", ctypes.c_size_t), ("mappedSourceCells", ctypes.c_size_t),
+                ("stagedCells", ctypes.c_size_t), ("tileW", ctypes.c_size_t), ("tileH", ctypes.c_size_t)]
 
 
 class Process2d(ctypes.Structure):
@@ -159,7 +160,11 @@ class RegridPlan:
             load().fimex_amd_regrid_plan_destroy(self._h)
             self._h = _V()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may be gone already
+            pass
 
     def info(self):
         i = PlanInfo()
@@ -195,7 +200,11 @@ class VectorPlan:
             load().fimex_amd_vector_plan_destroy(self._h)
             self._h = _V()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def reproject_values_host(self, u, v):
         u, v = _f32(u).copy(), _f32(v).copy()

@@ -446,6 +446,9 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
         const auto& s = plan.staged;  // the staged kernel reads LDS offsets instead of pos, plus the tile tables
         plan.info.planBytes = plan.info.planBytes - plan.pos.bytes() + s.ldsA.bytes() + s.ldsB.bytes() + s.tileHdr.bytes() +
                               (size_t)s.nTiles * 2 * 4 * 48;
+        plan.info.stagedCells = s.stagedCells;
+        plan.info.tileW = s.tileW;
+        plan.info.tileH = s.tileH;
     }
 }
 

@@ -77,6 +77,11 @@ SYMBOLS = {
     "fimex_amd_nan2bad_device": (ctypes.c_int, [_V, _Z, ctypes.c_float, _V]),
     "fimex_amd_points2position_device": (ctypes.c_int, [_V, _Z, _D, ctypes.c_int, ctypes.c_int, _V]),
     "fimex_amd_points2position_host": (ctypes.c_int, [_D, _Z, _D, ctypes.c_int, ctypes.c_int]),
+    "fimex_amd_data2interpolation_device": (ctypes.c_int, [_V, ctypes.c_int, _Z, ctypes.c_double, _V, _V]),
+    "fimex_amd_interpolation2data_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, _V, _V]),
+    "fimex_amd_regrid_slice_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, _Z, ctypes.c_double, ctypes.POINTER(Process2d), _Z,
+                                                         _V, ctypes.c_int, ctypes.c_double, _V, ctypes.c_int,
+                                                         ctypes.POINTER(Process2d), _Z, _V, _Z, _ZP]),
     "fimex_amd_scan_sum_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _ZP, _V]),
 }
 
@@ -248,6 +253,45 @@ def regrid_slice_host(plan, inData, badValue=float("nan"), pre=(), post=(), coun
     _check(load().fimex_amd_regrid_slice_host(*args, None, 0, ctypes.byref(n)))
     out = np.empty(n.value, dtype=np.float32)
     _check(load().fimex_amd_regrid_slice_host(*args, _fp(out), out.size, ctypes.byref(n)))
+    return out.reshape(-1, plan.outY, plan.outX)
+
+
+# CDMDataType codes (include/fimex/CDMDataType.h:35-49) and their numpy element types
+CDM_CHAR, CDM_SHORT, CDM_INT, CDM_FLOAT, CDM_DOUBLE, CDM_UCHAR, CDM_USHORT, CDM_UINT, CDM_INT64, CDM_UINT64 = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11
+CDM_DTYPES = {CDM_CHAR: np.int8, CDM_SHORT: np.int16, CDM_INT: np.int32, CDM_FLOAT: np.float32, CDM_DOUBLE: np.float64,
+              CDM_UCHAR: np.uint8, CDM_USHORT: np.uint16, CDM_UINT: np.uint32, CDM_INT64: np.int64, CDM_UINT64: np.uint64}
+
+
+def cdm_type_of(dtype):
+    for code, dt in CDM_DTYPES.items():
+        if np.dtype(dt) == np.dtype(dtype):
+            return code
+    raise TypeError("no CDMDataType for %s" % dtype)
+
+
+def data2interpolation_device(d_in, cdmType, n, badValue, d_out, stream=0):
+    _check(load().fimex_amd_data2interpolation_device(d_in, cdmType, n, badValue, d_out, stream))
+
+
+def interpolation2data_device(d_in, n, cdmType, badValue, d_out, stream=0):
+    _check(load().fimex_amd_interpolation2data_device(d_in, n, cdmType, badValue, d_out, stream))
+
+
+def regrid_slice_typed_host(plan, inData, badValue, pre=(), post=(), counterpart=None, badValueCounterpart=float("nan"),
+                            vec=None, isXComponent=True):
+    """fimex_amd_regrid_slice_typed_host: the slice in the variable's stored type in, the same type out."""
+    a = np.ascontiguousarray(inData).ravel()
+    t = cdm_type_of(a.dtype)
+    c = np.ascontiguousarray(counterpart).ravel() if counterpart is not None else None
+    pre_a = (Process2d * len(pre))(*pre) if pre else None
+    post_a = (Process2d * len(post))(*post) if post else None
+    n = _Z(0)
+    args = (plan._h, a.ctypes.data, t, a.size, badValue, pre_a, len(pre), c.ctypes.data if c is not None else None,
+            cdm_type_of(c.dtype) if c is not None else 0, badValueCounterpart, vec._h if vec is not None else None,
+            1 if isXComponent else 0, post_a, len(post))
+    _check(load().fimex_amd_regrid_slice_typed_host(*args, None, 0, ctypes.byref(n)))
+    out = np.empty(n.value, dtype=a.dtype)
+    _check(load().fimex_amd_regrid_slice_typed_host(*args, out.ctypes.data, out.size, ctypes.byref(n)))
     return out.reshape(-1, plan.outY, plan.outX)
 
 

@@ -422,6 +422,82 @@ int fimex_amd_points2position_device(double* d_points, size_t n, const double* a
     });
 }
 
+namespace {
+
+// CDMInterpolator::getDataSlice, src/CDMInterpolator.cc:251-285, on one step of one variable; typed == false is the
+// float-in / float-out form (conversions reduced to mifi_bad2nanf / mifi_nanf2bad with a float fill value)
+void regrid_slice(const fimex_amd_regrid_plan* plan, bool typed, const void* inData, int dataType, size_t size, double badValue,
+                  const fimex_amd_process2d* pre, size_t nPre, const void* counterpart, int counterpartType,
+                  double badValueCounterpart, const fimex_amd_vector_plan* vec, int isXComponent,
+                  const fimex_amd_process2d* post, size_t nPost, void* outData, size_t outCapacity, size_t* newSize)
+{
+    FA_REQUIRE(plan != nullptr && newSize != nullptr, "NULL argument");
+    FA_REQUIRE((nPre == 0 || pre != nullptr) && (nPost == 0 || post != nullptr), "NULL process list");
+    const size_t inLayer = plan->inX * plan->inY, outLayer = plan->outX * plan->outY;
+    const size_t nz = size / inLayer;
+    *newSize = outLayer * nz;
+    if (outData == nullptr) return;
+    FA_REQUIRE(outCapacity >= *newSize, "output buffer too small");
+    const size_t elem = typed ? cdm_type_size(dataType) : sizeof(float);
+    if (nz == 0) return;
+    FA_REQUIRE(inData != nullptr, "inData is NULL");
+    const bool vector = counterpart != nullptr && vec != nullptr;
+    if (vector) FA_REQUIRE(vec->device == plan->device && vec->ox == plan->outX && vec->oy == plan->outY,
+                           "vector reprojection does not match the regrid plan");
+    const size_t elemOther = (vector && typed) ? cdm_type_size(counterpartType) : sizeof(float);
+    ScopedDevice dev(plan->device);
+    ScopedStream stream;
+    hipStream_t st = stream.get();
+    auto run = [&](const fimex_amd_process2d* list, size_t n, float* d, size_t nx, size_t ny) {
+        for (size_t i = 0; i < n; ++i) {
+            const fimex_amd_process2d& p = list[i];
+            switch (p.kind) {
+            case FIMEX_AMD_PROCESS_FILL2D: run_fill2d(nx, ny, nz, d, p.relaxCrit, p.corrEff, p.maxLoop, nullptr, st); break;
+            case FIMEX_AMD_PROCESS_CREEPFILL2D: run_creepfill(nx, ny, nz, d, false, 0.f, p.repeat, p.setWeight, nullptr, st); break;
+            case FIMEX_AMD_PROCESS_CREEPFILLVAL2D: run_creepfill(nx, ny, nz, d, true, p.defaultVal, p.repeat, p.setWeight, nullptr, st); break;
+            default: throw Error("unknown 2-D process kind " + std::to_string(p.kind));
+            }
+        }
+    };
+    // one component: upload in its stored type, -> float with the fill value as NaN, pre-processes, regrid
+    auto regrid = [&](const void* h_in, int type, size_t bytesPerElem, double bad, DeviceArray<float>& d_out) {
+        DeviceArray<float> d_in(nz * inLayer);
+        DeviceArray<unsigned char> d_raw;
+        if (typed && type != FIMEX_AMD_CDM_FLOAT) {
+            d_raw.allocate(nz * inLayer * bytesPerElem);
+            FA_HIP(hipMemcpyAsync(d_raw.get(), h_in, d_raw.bytes(), hipMemcpyHostToDevice, st));
+            launch_data2interpolation(d_raw.get(), type, d_in.size(), bad, d_in.get(), st);
+        } else {
+            FA_HIP(hipMemcpyAsync(d_in.get(), h_in, d_in.bytes(), hipMemcpyHostToDevice, st));
+            launch_bad2nan(d_in.get(), d_in.size(), (float)bad, st);
+        }
+        run(pre, nPre, d_in.get(), plan->inX, plan->inY);
+        d_out.allocate(nz * outLayer);
+        apply_device(*plan, d_in.get(), nz, d_out.get(), st);
+        FA_HIP(hipStreamSynchronize(st));  // d_in / d_raw are released on return
+    };
+    DeviceArray<float> d_main, d_other;
+    regrid(inData, dataType, elem, badValue, d_main);
+    if (vector) {
+        regrid(counterpart, counterpartType, elemOther, badValueCounterpart, d_other);
+        if (isXComponent) launch_vector_values(*vec, d_main.get(), d_other.get(), nz, st);
+        else launch_vector_values(*vec, d_other.get(), d_main.get(), nz, st);
+    }
+    run(post, nPost, d_main.get(), plan->outX, plan->outY);
+    if (typed) {
+        DeviceArray<unsigned char> d_typed(d_main.size() * elem);
+        launch_interpolation2data(d_main.get(), d_main.size(), dataType, badValue, d_typed.get(), st);
+        FA_HIP(hipMemcpyAsync(outData, d_typed.get(), d_typed.bytes(), hipMemcpyDeviceToHost, st));
+        stream.sync();
+    } else {
+        launch_nan2bad(d_main.get(), d_main.size(), (float)badValue, st);
+        FA_HIP(hipMemcpyAsync(outData, d_main.get(), d_main.bytes(), hipMemcpyDeviceToHost, st));
+        stream.sync();
+    }
+}
+
+}  // namespace
+
 int fimex_amd_regrid_slice_host(const fimex_amd_regrid_plan* plan, const float* inData, size_t size, float badValue,
                                 const fimex_amd_process2d* pre, size_t nPre, const float* counterpart,
                                 float badValueCounterpart, const fimex_amd_vector_plan* vec, int isXComponent,
@@ -429,53 +505,42 @@ int fimex_amd_regrid_slice_host(const fimex_amd_regrid_plan* plan, const float* 
                                 size_t* newSize)
 {
     return c_guard([&] {
-        FA_REQUIRE(plan != nullptr && newSize != nullptr, "NULL argument");
-        FA_REQUIRE((nPre == 0 || pre != nullptr) && (nPost == 0 || post != nullptr), "NULL process list");
-        const size_t inLayer = plan->inX * plan->inY, outLayer = plan->outX * plan->outY;
-        const size_t nz = size / inLayer;
-        *newSize = outLayer * nz;
-        if (outData == nullptr) return;
-        FA_REQUIRE(outCapacity >= *newSize, "output buffer too small");
-        if (nz == 0) return;
-        FA_REQUIRE(inData != nullptr, "inData is NULL");
-        const bool vector = counterpart != nullptr && vec != nullptr;
-        if (vector) FA_REQUIRE(vec->device == plan->device && vec->ox == plan->outX && vec->oy == plan->outY,
-                               "vector reprojection does not match the regrid plan");
-        ScopedDevice dev(plan->device);
-        ScopedStream stream;
-        hipStream_t st = stream.get();
-        auto run = [&](const fimex_amd_process2d* list, size_t n, float* d, size_t nx, size_t ny) {
-            for (size_t i = 0; i < n; ++i) {
-                const fimex_amd_process2d& p = list[i];
-                switch (p.kind) {
-                case FIMEX_AMD_PROCESS_FILL2D: run_fill2d(nx, ny, nz, d, p.relaxCrit, p.corrEff, p.maxLoop, nullptr, st); break;
-                case FIMEX_AMD_PROCESS_CREEPFILL2D: run_creepfill(nx, ny, nz, d, false, 0.f, p.repeat, p.setWeight, nullptr, st); break;
-                case FIMEX_AMD_PROCESS_CREEPFILLVAL2D: run_creepfill(nx, ny, nz, d, true, p.defaultVal, p.repeat, p.setWeight, nullptr, st); break;
-                default: throw Error("unknown 2-D process kind " + std::to_string(p.kind));
-                }
-            }
-        };
-        // one component: upload, fill value -> NaN, pre-processes, regrid
-        auto regrid = [&](const float* h_in, float bad, DeviceArray<float>& d_out) {
-            DeviceArray<float> d_in(nz * inLayer);
-            FA_HIP(hipMemcpyAsync(d_in.get(), h_in, d_in.bytes(), hipMemcpyHostToDevice, st));
-            launch_bad2nan(d_in.get(), d_in.size(), bad, st);
-            run(pre, nPre, d_in.get(), plan->inX, plan->inY);
-            d_out.allocate(nz * outLayer);
-            apply_device(*plan, d_in.get(), nz, d_out.get(), st);
-            FA_HIP(hipStreamSynchronize(st));  // d_in is released on return
-        };
-        DeviceArray<float> d_main, d_other;
-        regrid(inData, badValue, d_main);
-        if (vector) {
-            regrid(counterpart, badValueCounterpart, d_other);
-            if (isXComponent) launch_vector_values(*vec, d_main.get(), d_other.get(), nz, st);
-            else launch_vector_values(*vec, d_other.get(), d_main.get(), nz, st);
-        }
-        run(post, nPost, d_main.get(), plan->outX, plan->outY);
-        launch_nan2bad(d_main.get(), d_main.size(), badValue, st);
-        FA_HIP(hipMemcpyAsync(outData, d_main.get(), d_main.bytes(), hipMemcpyDeviceToHost, st));
-        stream.sync();
+        regrid_slice(plan, false, inData, FIMEX_AMD_CDM_FLOAT, size, badValue, pre, nPre, counterpart, FIMEX_AMD_CDM_FLOAT,
+                     badValueCounterpart, vec, isXComponent, post, nPost, outData, outCapacity, newSize);
+    });
+}
+
+int fimex_amd_regrid_slice_typed_host(const fimex_amd_regrid_plan* plan, const void* inData, int dataType, size_t size, double badValue,
+                                      const fimex_amd_process2d* pre, size_t nPre, const void* counterpart, int counterpartType,
+                                      double badValueCounterpart, const fimex_amd_vector_plan* vec, int isXComponent,
+                                      const fimex_amd_process2d* post, size_t nPost, void* outData, size_t outCapacity,
+                                      size_t* newSize)
+{
+    return c_guard([&] {
+        regrid_slice(plan, true, inData, dataType, size, badValue, pre, nPre, counterpart, counterpartType, badValueCounterpart,
+                     vec, isXComponent, post, nPost, outData, outCapacity, newSize);
+    });
+}
+
+int fimex_amd_data2interpolation_device(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, void* stream)
+{
+    return c_guard([&] {
+        (void)cdm_type_size(cdmType);
+        if (n == 0) return;
+        FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        launch_data2interpolation(d_in, cdmType, n, badValue, d_out, as_stream(stream));
+    });
+}
+
+int fimex_amd_interpolation2data_device(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, void* stream)
+{
+    return c_guard([&] {
+        (void)cdm_type_size(cdmType);
+        if (n == 0) return;
+        FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
+        (void)current_device_checked();
+        launch_interpolation2data(d_in, n, cdmType, badValue, d_out, as_stream(stream));
     });
 }
 

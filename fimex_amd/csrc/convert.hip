@@ -4,6 +4,9 @@
 // mifi_points2position (src/interpolation.c:104-217).
 #include "plan.hpp"
 
+#include <string>
+#include <type_traits>
+
 namespace fimex_amd {
 
 namespace {
@@ -72,6 +75,109 @@ void launch_replace(float* d, size_t n, float bad, hipStream_t stream)
     FA_HIP(hipGetLastError());
 }
 
+// ---- typed edges of a slice: data2InterpolationArray / interpolationArray2Data, src/CDMInterpolator.cc:115-124
+// T -> float is Data::asFloat() = static_cast<float> per element (src/DataImpl.h:99,132,384-389; include/fimex/Utils.h:94-116),
+// fused with mifi_bad2nanf on the fill value; four elements per lane, one vector load and one float4 store.
+template <typename T>
+using Vec4 = T __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ float as_float_nan(T v, float bad, bool hasBad)
+{
+    const float f = (float)v;
+    return (hasBad && f == bad) ? undefined_f() : f;  // interpolation.c:1778; a NaN fill value leaves the data alone (:1776)
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock) to_float_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n, float bad, bool hasBad)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if (VEC) {
+        const size_t n4 = n / 4;
+        const Vec4<T>* in4 = reinterpret_cast<const Vec4<T>*>(in);
+        float4* out4 = reinterpret_cast<float4*>(out);
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+            const Vec4<T> v = in4[i];
+            out4[i] = make_float4(as_float_nan(v.x, bad, hasBad), as_float_nan(v.y, bad, hasBad), as_float_nan(v.z, bad, hasBad),
+                                  as_float_nan(v.w, bad, hasBad));
+        }
+        for (size_t j = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) out[j] = as_float_nan(in[j], bad, hasBad);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = as_float_nan(in[i], bad, hasBad);
+    }
+}
+
+// MetNoFimex::round(double) (include/fimex/Utils.h:72-75): lround, then long -> int.  Outside the range of long the
+// reference is unspecified; LONG_MIN (what glibc/x86-64 yields) is kept (DESIGN.md divergence D6).
+__device__ __forceinline__ int mifi_round(double num)
+{
+    const long long r = (fabs(num) < 9223372036854775808.0) ? llround(num) : (-9223372036854775807LL - 1);
+    return (int)r;
+}
+
+// float -> T is ScaleValue<float, T>(NaN, 1, 0, fill, 1, 0) (include/fimex/Utils.h:444-464): NaN -> fill, else
+// data_caster<T, double>(1.0 * v + 0.0): through mifi_round for integer T, a plain cast otherwise
+template <typename T>
+__device__ __forceinline__ T from_float_fill(float v, T fill)
+{
+    if (isnan(v)) return fill;
+    const double d = 1.0 * (double)v + 0.0;  // turns -0.0 into +0.0, as the reference does
+    if (std::is_integral<T>::value) return (T)mifi_round(d);
+    return (T)d;
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kBlock) from_float_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n, T fill)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if (VEC) {
+        const size_t n4 = n / 4;
+        const float4* in4 = reinterpret_cast<const float4*>(in);
+        Vec4<T>* out4 = reinterpret_cast<Vec4<T>*>(out);
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+            const float4 v = in4[i];
+            Vec4<T> r;
+            r.x = from_float_fill<T>(v.x, fill);
+            r.y = from_float_fill<T>(v.y, fill);
+            r.z = from_float_fill<T>(v.z, fill);
+            r.w = from_float_fill<T>(v.w, fill);
+            out4[i] = r;
+        }
+        for (size_t j = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) out[j] = from_float_fill<T>(in[j], fill);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = from_float_fill<T>(in[i], fill);
+    }
+}
+
+uint32_t stream_blocks(size_t n)
+{
+    const size_t groups = ceil_div(n, (size_t)4 * kBlock);
+    return (uint32_t)(groups < 256 * 8 ? (groups ? groups : 1) : 256 * 8);
+}
+
+template <typename T>
+void launch_to_float_t(const void* d_in, size_t n, double badValue, float* d_out, hipStream_t stream)
+{
+    const T* in = static_cast<const T*>(d_in);
+    const float bad = (float)badValue;  // the double fill value narrows to mifi_bad2nanf's float parameter (CDMInterpolator.cc:117)
+    const bool hasBad = !(bad != bad);
+    const bool vec = reinterpret_cast<uintptr_t>(in) % (4 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0;
+    if (vec) to_float_kernel<T, true><<<stream_blocks(n), kBlock, 0, stream>>>(in, d_out, n, bad, hasBad);
+    else to_float_kernel<T, false><<<stream_blocks(n), kBlock, 0, stream>>>(in, d_out, n, bad, hasBad);
+    FA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void launch_from_float_t(const float* d_in, size_t n, double badValue, void* d_out, hipStream_t stream)
+{
+    T* out = static_cast<T*>(d_out);
+    const T fill = static_cast<T>(badValue);  // ScaleValue's newFill_ (Utils.h:456)
+    const bool vec = reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(d_in) % 16 == 0;
+    if (vec) from_float_kernel<T, true><<<stream_blocks(n), kBlock, 0, stream>>>(d_in, out, n, fill);
+    else from_float_kernel<T, false><<<stream_blocks(n), kBlock, 0, stream>>>(d_in, out, n, fill);
+    FA_HIP(hipGetLastError());
+}
+
 // axis order compare, src/interpolation.c:104-117: dir = +1 ascending, -1 descending
 __device__ __forceinline__ int axis_compare(double key, double elem, int dir)
 {
@@ -123,6 +229,53 @@ __global__ void __launch_bounds__(kBlock) points2position_kernel(P2PArgs a)
 
 void launch_bad2nan(float* d, size_t n, float bad, hipStream_t stream) { launch_replace<true>(d, n, bad, stream); }
 void launch_nan2bad(float* d, size_t n, float bad, hipStream_t stream) { launch_replace<false>(d, n, bad, stream); }
+
+size_t cdm_type_size(int cdmType)
+{
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: case FIMEX_AMD_CDM_UCHAR: return 1;
+    case FIMEX_AMD_CDM_SHORT: case FIMEX_AMD_CDM_USHORT: return 2;
+    case FIMEX_AMD_CDM_INT: case FIMEX_AMD_CDM_UINT: case FIMEX_AMD_CDM_FLOAT: return 4;
+    case FIMEX_AMD_CDM_DOUBLE: case FIMEX_AMD_CDM_INT64: case FIMEX_AMD_CDM_UINT64: return 8;
+    default: throw Error("data type " + std::to_string(cdmType) + " cannot be regridded (CDM_STRING / CDM_NAT have no float form)");
+    }
+}
+
+void launch_data2interpolation(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, hipStream_t stream)
+{
+    if (n == 0) return;
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: launch_to_float_t<signed char>(d_in, n, badValue, d_out, stream); break;  // char is signed on the reference's platforms
+    case FIMEX_AMD_CDM_SHORT: launch_to_float_t<short>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_INT: launch_to_float_t<int>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_FLOAT: launch_to_float_t<float>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_DOUBLE: launch_to_float_t<double>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_UCHAR: launch_to_float_t<unsigned char>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_USHORT: launch_to_float_t<unsigned short>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_UINT: launch_to_float_t<unsigned int>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_INT64: launch_to_float_t<long long>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_UINT64: launch_to_float_t<unsigned long long>(d_in, n, badValue, d_out, stream); break;
+    default: (void)cdm_type_size(cdmType);
+    }
+}
+
+void launch_interpolation2data(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, hipStream_t stream)
+{
+    if (n == 0) return;
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: launch_from_float_t<signed char>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_SHORT: launch_from_float_t<short>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_INT: launch_from_float_t<int>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_FLOAT: launch_from_float_t<float>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_DOUBLE: launch_from_float_t<double>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_UCHAR: launch_from_float_t<unsigned char>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_USHORT: launch_from_float_t<unsigned short>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_UINT: launch_from_float_t<unsigned int>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_INT64: launch_from_float_t<long long>(d_in, n, badValue, d_out, stream); break;
+    case FIMEX_AMD_CDM_UINT64: launch_from_float_t<unsigned long long>(d_in, n, badValue, d_out, stream); break;
+    default: (void)cdm_type_size(cdmType);
+    }
+}
 
 void launch_points2position(double* d_points, size_t n, const double* axis, int num, int axisType, hipStream_t stream)
 {

@@ -95,6 +95,9 @@ void launch_vector_direction(const fimex_amd_vector_plan& plan, float* d_angles,
 void launch_bad2nan(float* d, size_t n, float bad, hipStream_t stream);
 void launch_nan2bad(float* d, size_t n, float bad, hipStream_t stream);
 void launch_points2position(double* d_points, size_t n, const double* h_axis, int num, int axisType, hipStream_t stream);
+size_t cdm_type_size(int cdmType);  // throws for types without a float form
+void launch_data2interpolation(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, hipStream_t stream);
+void launch_interpolation2data(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, hipStream_t stream);
 
 // fill.hip
 void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,

@@ -217,6 +217,31 @@ int fimex_amd_regrid_slice_host(const fimex_amd_regrid_plan* plan, const float* 
 int fimex_amd_bad2nan_device(float* d_data, size_t n, float badVal, void* stream);
 int fimex_amd_nan2bad_device(float* d_data, size_t n, float badVal, void* stream);
 
+/* ------------------------------------------------ typed slices */
+/** CDMDataType, include/fimex/CDMDataType.h:35-49 (same values). */
+typedef enum fimex_amd_datatype {
+    FIMEX_AMD_CDM_NAT = 0, FIMEX_AMD_CDM_CHAR, FIMEX_AMD_CDM_SHORT, FIMEX_AMD_CDM_INT, FIMEX_AMD_CDM_FLOAT,
+    FIMEX_AMD_CDM_DOUBLE, FIMEX_AMD_CDM_STRING, FIMEX_AMD_CDM_UCHAR, FIMEX_AMD_CDM_USHORT, FIMEX_AMD_CDM_UINT,
+    FIMEX_AMD_CDM_INT64, FIMEX_AMD_CDM_UINT64
+} fimex_amd_datatype;
+/** data2InterpolationArray, src/CDMInterpolator.cc:115-119: n device elements of cdmType -> float (Data::asFloat())
+ *  with the variable's fill value as NaN (mifi_bad2nanf), in one pass. */
+int fimex_amd_data2interpolation_device(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, void* stream);
+/** interpolationArray2Data, src/CDMInterpolator.cc:121-124: float -> cdmType as
+ *  DataImpl<float>::convertDataType(MIFI_UNDEFINED_F, 1, 0, cdmType, badValue, 1, 0) does (NaN -> fill value,
+ *  integers rounded through MetNoFimex::round), in one pass. */
+int fimex_amd_interpolation2data_device(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, void* stream);
+/** fimex_amd_regrid_slice_host on the variable's stored type: everything CDMInterpolator::getDataSlice
+ *  (src/CDMInterpolator.cc:251-285) does with a slice, including both conversions; only `size` elements of dataType
+ *  cross PCIe in, *newSize elements of dataType come back (half the bytes for packed shorts).  size and outCapacity
+ *  count elements.  The counterpart of a vector variable may be stored in another type. */
+int fimex_amd_regrid_slice_typed_host(const fimex_amd_regrid_plan* plan, const void* inData, int dataType, size_t size, double badValue,
+                                      const fimex_amd_process2d* pre, size_t nPre,
+                                      const void* counterpart, int counterpartType, double badValueCounterpart,
+                                      const fimex_amd_vector_plan* vec, int isXComponent,
+                                      const fimex_amd_process2d* post, size_t nPost,
+                                      void* outData, size_t outCapacity, size_t* newSize);
+
 /* ------------------------------------------------------- plan build helpers */
 /** mifi_points2position, include/fimex/interpolation.h:415, src/interpolation.c:148-217:
  *  n device doubles (radians or metres) -> fractional axis indices, in place. axis: host, num entries. */

@@ -77,6 +77,10 @@ def _declare(L):
     L.orc_bad2nanf.restype = _Z
     L.orc_nanf2bad.argtypes = [_F, _F, ctypes.c_float]
     L.orc_nanf2bad.restype = _Z
+    L.orc_data2interpolation_array.argtypes = [ctypes.c_void_p, ctypes.c_int, _Z, ctypes.c_double, _F]
+    L.orc_data2interpolation_array.restype = ctypes.c_int
+    L.orc_interpolation_array2data.argtypes = [_F, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    L.orc_interpolation_array2data.restype = ctypes.c_int
     L.orc_vector_matrix_from_deltas.argtypes = [_D] * 6 + [ctypes.c_double, ctypes.c_double, ctypes.c_int, _Z, _D]
     L.orc_vector_matrix_from_deltas.restype = ctypes.c_int
 
@@ -211,6 +215,39 @@ def bad2nan(a, bad):
     flat = a.reshape(-1)
     lib().orc_bad2nanf(_f(flat), ctypes.cast(flat.ctypes.data + flat.nbytes, _F), bad)
     return a
+
+
+# CDMDataType codes (include/fimex/CDMDataType.h:35-49) <-> numpy dtypes
+CDM_CHAR, CDM_SHORT, CDM_INT, CDM_FLOAT, CDM_DOUBLE, CDM_UCHAR, CDM_USHORT, CDM_UINT, CDM_INT64, CDM_UINT64 = 1, 2, 3, 4, 5, 7, 8, 9, 10, 11
+CDM_DTYPES = {CDM_CHAR: np.int8, CDM_SHORT: np.int16, CDM_INT: np.int32, CDM_FLOAT: np.float32, CDM_DOUBLE: np.float64,
+              CDM_UCHAR: np.uint8, CDM_USHORT: np.uint16, CDM_UINT: np.uint32, CDM_INT64: np.int64, CDM_UINT64: np.uint64}
+
+
+def cdm_type_of(dtype):
+    for code, dt in CDM_DTYPES.items():
+        if np.dtype(dt) == np.dtype(dtype):
+            return code
+    raise TypeError("no CDMDataType for %s" % dtype)
+
+
+def data2interpolation_array(a, bad):
+    """data2InterpolationArray: typed array -> float32 with the fill value as NaN."""
+    a = np.ascontiguousarray(a)
+    out = np.empty(a.shape, np.float32)
+    rc = lib().orc_data2interpolation_array(ctypes.c_void_p(a.ctypes.data), cdm_type_of(a.dtype), ctypes.c_size_t(a.size),
+                                            ctypes.c_double(bad), _f(out.reshape(-1)))
+    assert rc == OK
+    return out
+
+
+def interpolation_array2data(a, newType, bad):
+    """interpolationArray2Data: float32 -> array of the CDMDataType newType with NaN as the fill value."""
+    a = _c32(a)
+    out = np.empty(a.shape, CDM_DTYPES[newType])
+    rc = lib().orc_interpolation_array2data(_f(a.reshape(-1)), ctypes.c_size_t(a.size), newType, ctypes.c_double(bad),
+                                            ctypes.c_void_p(out.ctypes.data))
+    assert rc == OK
+    return out
 
 
 def nan2bad(a, bad):

@@ -640,3 +640,79 @@ size_t orc_nanf2bad(float* p, float* end, float badVal)
     if (!isnan(badVal)) for (; p != end; ++p) if (isnan(*p)) *p = badVal;
     return 0;
 }
+
+/* ------------------------------------------------------- typed slice edges (n1) */
+size_t orc_cdm_type_size(int type)
+{
+    switch (type) {
+    case ORC_CDM_CHAR: case ORC_CDM_UCHAR: return 1;
+    case ORC_CDM_SHORT: case ORC_CDM_USHORT: return 2;
+    case ORC_CDM_INT: case ORC_CDM_UINT: case ORC_CDM_FLOAT: return 4;
+    case ORC_CDM_DOUBLE: case ORC_CDM_INT64: case ORC_CDM_UINT64: return 8;
+    default: return 0;
+    }
+}
+
+/* src/CDMInterpolator.cc:115-119.  Data::asFloat() is ArrayTypeConverter<float, C> (src/DataImpl.h:99,132,384-389):
+ * data_caster<float, C> = static_cast<float> per element (include/fimex/Utils.h:94-116, no rounding step since the
+ * target is not an integer type); then mifi_bad2nanf(begin, end, badValue) with the double fill value converted to the
+ * float parameter (src/interpolation.c:1775-1783). */
+int orc_data2interpolation_array(const void* in, int type, size_t n, double badValue, float* out)
+{
+#define ORC_AS_FLOAT(T) { const T* p = (const T*)in; for (size_t i = 0; i < n; ++i) out[i] = (float)p[i]; } break
+    switch (type) {
+    case ORC_CDM_CHAR: ORC_AS_FLOAT(char);
+    case ORC_CDM_SHORT: ORC_AS_FLOAT(short);
+    case ORC_CDM_INT: ORC_AS_FLOAT(int);
+    case ORC_CDM_FLOAT: ORC_AS_FLOAT(float);
+    case ORC_CDM_DOUBLE: ORC_AS_FLOAT(double);
+    case ORC_CDM_UCHAR: ORC_AS_FLOAT(unsigned char);
+    case ORC_CDM_USHORT: ORC_AS_FLOAT(unsigned short);
+    case ORC_CDM_UINT: ORC_AS_FLOAT(unsigned int);
+    case ORC_CDM_INT64: ORC_AS_FLOAT(long long);
+    case ORC_CDM_UINT64: ORC_AS_FLOAT(unsigned long long);
+    default: return ORC_ERROR;
+    }
+#undef ORC_AS_FLOAT
+    orc_bad2nanf(out, out + n, (float)badValue);
+    return ORC_OK;
+}
+
+/* MetNoFimex::round(double), include/fimex/Utils.h:72-75: int round(double) { return ::lround(num); }.
+ * D6: lround of a value outside the range of long is unspecified in C; glibc on x86-64 yields LONG_MIN, kept here. */
+static int orc_mifi_round(double num)
+{
+    long r;
+    if (!(fabs(num) < 9223372036854775808.0)) r = (long)(-9223372036854775807LL - 1);
+    else r = lround(num);
+    return (int)r; /* long -> int: wraps (gcc), like the reference's implicit conversion */
+}
+
+/* src/CDMInterpolator.cc:121-124 -> DataImpl<float>::convertDataType(MIFI_UNDEFINED_F, 1., 0., newType, badValue, 1., 0.)
+ * (src/DataImpl.h:314-319, 329-348) -> ScaleValue<float, OUT> (include/fimex/Utils.h:444-464):
+ *   (in == oldFill || isnan(in)) ? static_cast<OUT>(newFill) : data_caster<OUT, double>()(1.0 * in + 0.0)
+ * with oldScale/newScale = 1, (oldOffset - newOffset)/newScale = 0; data_caster rounds through MetNoFimex::round (an int)
+ * when OUT is an integer type (Utils.h:94-116).  Note 1.0 * in + 0.0 turns -0.0 into +0.0. */
+int orc_interpolation_array2data(const float* in, size_t n, int newType, double badValue, void* out)
+{
+#define ORC_SCALE_INT(T) { T* p = (T*)out; const T fill = (T)badValue; \
+        for (size_t i = 0; i < n; ++i) p[i] = isnan(in[i]) ? fill : (T)orc_mifi_round(1.0 * in[i] + 0.0); } break
+#define ORC_SCALE_FLT(T) { T* p = (T*)out; const T fill = (T)badValue; \
+        for (size_t i = 0; i < n; ++i) p[i] = isnan(in[i]) ? fill : (T)(1.0 * in[i] + 0.0); } break
+    switch (newType) {
+    case ORC_CDM_CHAR: ORC_SCALE_INT(char);
+    case ORC_CDM_SHORT: ORC_SCALE_INT(short);
+    case ORC_CDM_INT: ORC_SCALE_INT(int);
+    case ORC_CDM_FLOAT: ORC_SCALE_FLT(float);
+    case ORC_CDM_DOUBLE: ORC_SCALE_FLT(double);
+    case ORC_CDM_UCHAR: ORC_SCALE_INT(unsigned char);
+    case ORC_CDM_USHORT: ORC_SCALE_INT(unsigned short);
+    case ORC_CDM_UINT: ORC_SCALE_INT(unsigned int);
+    case ORC_CDM_INT64: ORC_SCALE_INT(long long);
+    case ORC_CDM_UINT64: ORC_SCALE_INT(unsigned long long);
+    default: return ORC_ERROR;
+    }
+#undef ORC_SCALE_INT
+#undef ORC_SCALE_FLT
+    return ORC_OK;
+}

@@ -78,6 +78,18 @@ int orc_points2position(double* points, size_t n, const double* axis, int num, i
 size_t orc_bad2nanf(float* begin, float* end, float badVal);
 size_t orc_nanf2bad(float* begin, float* end, float badVal);
 
+/* CDMDataType, include/fimex/CDMDataType.h:35-49 */
+enum {
+    ORC_CDM_NAT = 0, ORC_CDM_CHAR, ORC_CDM_SHORT, ORC_CDM_INT, ORC_CDM_FLOAT, ORC_CDM_DOUBLE, ORC_CDM_STRING,
+    ORC_CDM_UCHAR, ORC_CDM_USHORT, ORC_CDM_UINT, ORC_CDM_INT64, ORC_CDM_UINT64
+};
+/* bytes of one element of a CDMDataType, 0 for the types this path cannot carry */
+size_t orc_cdm_type_size(int type);
+/* data2InterpolationArray, src/CDMInterpolator.cc:115-119: Data::asFloat() then mifi_bad2nanf with the fill value */
+int orc_data2interpolation_array(const void* in, int type, size_t n, double badValue, float* out);
+/* interpolationArray2Data, src/CDMInterpolator.cc:121-124: convertDataType(NaN, 1, 0, newType, badValue, 1, 0) */
+int orc_interpolation_array2data(const float* in, size_t n, int newType, double badValue, void* out);
+
 /* rotation matrix from projected points: src/interpolation.c:330-438.
  * The PROJ.4 calls of the reference are replaced by caller-supplied arrays of
  * already projected points (x+dx,y) and (x,y+dy); see oracle/proj_oracle.py. */

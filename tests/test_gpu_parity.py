@@ -415,3 +415,100 @@ def test_concurrent_host_applies_are_reentrant(fa):
     [t.join() for t in ts]
     for got, want in zip(results, wants):
         assert cases.same(got, want)
+
+
+# ---------------------------------------------------------------- typed slice edges
+def _typed_field(dt, n, seed):
+    rng = np.random.default_rng(seed)
+    if np.issubdtype(dt, np.integer):
+        info = np.iinfo(dt)
+        a = rng.integers(max(info.min, -2 ** 62), min(info.max, 2 ** 62), n, dtype=np.int64 if info.min < 0 else np.uint64).astype(dt)
+        a[:3] = [info.min, info.max, 0]
+    else:
+        a = (rng.normal(0, 1, n) * 10.0 ** rng.integers(-5, 12, n)).astype(dt)
+        k = min(6, n)
+        a[:k] = [0.0, -0.0, np.nan, np.inf, -np.inf, 3.4e38][:k]
+    a[rng.choice(n, n // 50, replace=False)] = a[min(10, n - 1)]
+    return a
+
+
+@pytest.mark.parametrize("code", sorted(oracle.CDM_DTYPES))
+@pytest.mark.parametrize("n,off", [(100003, 0), (100003, 1), (5, 0), (4096, 3)])
+def test_data2interpolation_matches_oracle(fa, code, n, off):
+    import torch
+    dt = oracle.CDM_DTYPES[code]
+    a = _typed_field(dt, n + off, seed=code + n)
+    bad = float(a[min(10, n + off - 1)])
+    t = torch.from_numpy(a.view(np.uint8)).cuda()
+    out = torch.empty(n + 4, dtype=torch.float32, device="cuda")
+    for o_off in (0, 1):  # aligned (vector) and unaligned (scalar) destinations
+        fa.data2interpolation_device(t.data_ptr() + off * a.itemsize, code, n, bad, out.data_ptr() + 4 * o_off)
+        torch.cuda.synchronize()
+        got = out[o_off:o_off + n].cpu().numpy()
+        want = oracle.data2interpolation_array(a[off:], bad)
+        assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+@pytest.mark.parametrize("code", sorted(oracle.CDM_DTYPES))
+@pytest.mark.parametrize("n,off", [(100003, 0), (100001, 1), (7, 0)])
+def test_interpolation2data_matches_oracle(fa, code, n, off):
+    import torch
+    dt = oracle.CDM_DTYPES[code]
+    rng = np.random.default_rng(code * 7 + n)
+    f = (rng.normal(0, 1, n + off) * 10.0 ** rng.integers(-3, 6, n + off)).astype(np.float32)
+    f[rng.choice(n, n // 20 + 1, replace=False)] = np.nan
+    half = rng.integers(-300, 300, n // 10 + 1).astype(np.float32) + np.float32(0.5)  # exact ties: half away from zero
+    f[off:off + half.size] = half[:f.size - off]
+    f[-1] = -0.0
+    bad = 77.0
+    t = torch.from_numpy(f).cuda()
+    out = torch.zeros((n + 4) * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+    for o_off in (0, 1):
+        fa.interpolation2data_device(t.data_ptr() + 4 * off, n, code, bad, out.data_ptr() + o_off * np.dtype(dt).itemsize)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(dt)[o_off:o_off + n]
+        want = oracle.interpolation_array2data(f[off:], code, bad)
+        if np.issubdtype(dt, np.floating):
+            assert np.array_equal(got.view(np.uint32 if dt == np.float32 else np.uint64), want.view(np.uint32 if dt == np.float32 else np.uint64))
+        else:
+            assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dt,bad", [(np.int16, -32767.0), (np.float32, 9.96921e36), (np.float64, -999.0), (np.int32, -2147483647.0), (np.uint8, 255.0)])
+def test_regrid_slice_typed_matches_the_reference_sequence(fa, dt, bad):
+    """getDataSlice (src/CDMInterpolator.cc:251-285) on the stored type: asFloat + bad2nan, pre-process, regrid, rotation with
+    a counterpart stored in another type, post-process, convertDataType back -- against the same sequence of oracle calls."""
+    inX, inY, outX, outY, nz = 70, 50, 90, 60, 3
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=4)
+    rng = np.random.default_rng(11)
+    if np.issubdtype(dt, np.integer):
+        info = np.iinfo(dt)
+        u = rng.integers(max(info.min, -20000) // 2, min(info.max, 20000) // 2, (nz, inY, inX)).astype(dt)
+    else:
+        u = rng.normal(5, 40, (nz, inY, inX)).astype(dt)
+    u.reshape(-1)[rng.choice(u.size, u.size // 30, replace=False)] = dt(bad)
+    v = rng.normal(0, 30, (nz, inY, inX)).astype(np.float64)  # the counterpart lives in another type
+    v.reshape(-1)[rng.choice(v.size, v.size // 40, replace=False)] = -1e30
+    m = cases.rotation_matrix(outX, outY, seed=2)
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY)
+    vec = fa.VectorPlan(m, outX, outY)
+    pre = [fa.creepfill2d_process(2, 1)]
+    post = [fa.fill2d_process(4.0, 1.6, 30)]
+    got = fa.regrid_slice_typed_host(plan, u, bad, pre=pre, post=post, counterpart=v, badValueCounterpart=-1e30, vec=vec, isXComponent=True)
+    assert got.dtype == dt
+
+    def chain(a, b):
+        f = oracle.data2interpolation_array(a, b)
+        f = np.stack([oracle.creepfill2d(s, 2, 1)[0] for s in f])
+        return oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
+
+    ru, rv = oracle.vector_reproject_values(m, chain(u, bad), chain(v, -1e30), outX, outY)
+    ru = np.stack([oracle.fill2d(s, 4.0, 1.6, 30)[0] for s in ru])
+    want = oracle.interpolation_array2data(ru, oracle.cdm_type_of(dt), bad)
+    assert np.array_equal(got.view(np.uint8), want.reshape(got.shape).view(np.uint8))
+    # without a counterpart and processes: the float entry point agrees on float data
+    if dt == np.float32:
+        a = fa.regrid_slice_typed_host(plan, u, bad)
+        b = fa.regrid_slice_host(plan, u, bad)
+        ok = ~np.isnan(b)
+        assert cases.same(np.where(a == 0, 0 * a, a), np.where(b == 0, 0 * b, b))  # apart from -0.0 -> +0.0 (ScaleValue)

@@ -259,3 +259,60 @@ def test_points2position_longitude_wrap():
     got = oracle.points2position(p, axis, oracle.LONGITUDE)
     np.testing.assert_allclose(got, [359.5, -0.1, 0.0, 10.0, 10.0], atol=1e-9)
     assert oracle.points2position([np.nan, np.inf], axis, oracle.LONGITUDE).tolist() == [-999.0, -999.0]
+
+
+# ---------------------------------------------------------------- typed slice edges
+def _typed_samples(dt, rng, n=4000):
+    info = np.iinfo(dt) if np.issubdtype(dt, np.integer) else None
+    if info is not None:
+        a = rng.integers(max(info.min, -2 ** 62), min(info.max, 2 ** 62), n, dtype=np.int64 if info.min < 0 else np.uint64).astype(dt)
+        a[:4] = [info.min, info.max, 0, info.max // 2]
+    else:
+        a = (rng.normal(0, 1, n) * 10.0 ** rng.integers(-5, 12, n)).astype(dt)
+        a[:4] = [0.0, -0.0, np.nan, np.inf]
+    return a
+
+
+@pytest.mark.parametrize("code", sorted(oracle.CDM_DTYPES))
+def test_data2interpolation_array_is_cast_then_bad2nan(code):
+    """src/CDMInterpolator.cc:115-119 against numpy: astype(float32) is static_cast<float> (round to nearest even)."""
+    dt = oracle.CDM_DTYPES[code]
+    rng = np.random.default_rng(code)
+    a = _typed_samples(dt, rng)
+    bad = float(a[7])
+    got = oracle.data2interpolation_array(a, bad)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = a.astype(np.float32)
+        want[want == np.float32(bad)] = np.nan
+    assert cases.same(got, want)
+    assert np.isnan(got[7])
+    assert cases.same(oracle.data2interpolation_array(a, float("nan")), a.astype(np.float32))  # NaN fill value: untouched
+
+
+@pytest.mark.parametrize("code", sorted(oracle.CDM_DTYPES))
+def test_interpolation_array2data_rounds_half_away_and_restores_fill(code):
+    """src/CDMInterpolator.cc:121-124 -> ScaleValue<float, OUT> (include/fimex/Utils.h:444-464)."""
+    dt = oracle.CDM_DTYPES[code]
+    f = np.array([1.5, 2.5, -0.5, -1.5, -2.5, 0.49999997, np.nan, -0.0, 100.4, 126.5, -128.5], np.float32)
+    got = oracle.interpolation_array2data(f, code, 42.0)
+    assert got.dtype == dt and got[6] == dt(42)
+    if np.issubdtype(dt, np.integer):
+        want = np.array([2, 3, -1, -2, -3, 0, 42, 0, 100, 127, -129], np.int64)  # lround: half away from zero
+        assert np.array_equal(got, want.astype(np.int32).astype(dt))             # through int, then the narrowing cast wraps
+    else:
+        keep = ~np.isnan(f)
+        assert np.array_equal(got[keep], f[keep].astype(dt))
+        assert not np.signbit(got[7])  # 1.0 * (-0.0) + 0.0 = +0.0
+    # int64 / uint64 also pass through MetNoFimex::round's int: 3e9 wraps
+    if code == oracle.CDM_INT64:
+        assert oracle.interpolation_array2data(np.array([3e9], np.float32), code, 0.0)[0] == np.int64(3000000000 - 2 ** 32)
+
+
+def test_typed_round_trip_of_packed_shorts():
+    """short data with fill -32767 -> float/NaN -> short: identity (the common packed-variable case)."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(-32000, 32000, 10000).astype(np.int16)
+    a[rng.choice(a.size, 300, replace=False)] = -32767
+    f = oracle.data2interpolation_array(a, -32767.0)
+    assert np.isnan(f).sum() == (a == -32767).sum()
+    assert np.array_equal(oracle.interpolation_array2data(f, oracle.CDM_SHORT, -32767.0), a)

@@ -79,6 +79,8 @@ SYMBOLS = {
     "fimex_amd_points2position_host": (ctypes.c_int, [_D, _Z, _D, ctypes.c_int, ctypes.c_int]),
     "fimex_amd_data2interpolation_device": (ctypes.c_int, [_V, ctypes.c_int, _Z, ctypes.c_double, _V, _V]),
     "fimex_amd_interpolation2data_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, _V, _V]),
+    "fimex_amd_data2interpolation_host": (ctypes.c_int, [_V, ctypes.c_int, _Z, ctypes.c_double, _F]),
+    "fimex_amd_interpolation2data_host": (ctypes.c_int, [_F, _Z, ctypes.c_int, ctypes.c_double, _V]),
     "fimex_amd_regrid_slice_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, _Z, ctypes.c_double, ctypes.POINTER(Process2d), _Z,
                                                          _V, ctypes.c_int, ctypes.c_double, _V, ctypes.c_int,
                                                          ctypes.POINTER(Process2d), _Z, _V, _Z, _ZP]),

@@ -533,6 +533,40 @@ int fimex_amd_data2interpolation_device(const void* d_in, int cdmType, size_t n,
     });
 }
 
+int fimex_amd_data2interpolation_host(const void* in, int cdmType, size_t n, double badValue, float* out)
+{
+    return c_guard([&] {
+        const size_t elem = cdm_type_size(cdmType);
+        if (n == 0) return;
+        FA_REQUIRE(in != nullptr && out != nullptr, "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<unsigned char> d_in(n * elem);
+        DeviceArray<float> d_out(n);
+        FA_HIP(hipMemcpyAsync(d_in.get(), in, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
+        launch_data2interpolation(d_in.get(), cdmType, n, badValue, d_out.get(), stream.get());
+        FA_HIP(hipMemcpyAsync(out, d_out.get(), d_out.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_interpolation2data_host(const float* in, size_t n, int cdmType, double badValue, void* out)
+{
+    return c_guard([&] {
+        const size_t elem = cdm_type_size(cdmType);
+        if (n == 0) return;
+        FA_REQUIRE(in != nullptr && out != nullptr, "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<float> d_in(n);
+        DeviceArray<unsigned char> d_out(n * elem);
+        FA_HIP(hipMemcpyAsync(d_in.get(), in, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
+        launch_interpolation2data(d_in.get(), n, cdmType, badValue, d_out.get(), stream.get());
+        FA_HIP(hipMemcpyAsync(out, d_out.get(), d_out.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
 int fimex_amd_interpolation2data_device(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, void* stream)
 {
     return c_guard([&] {

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <iostream>
 #include <limits>
+#include <string>
 
 namespace FimexAmd {
 
@@ -140,30 +141,76 @@ void CDMInterpolator::processArray(const std::vector<std::shared_ptr<Interpolato
     for (const auto& p : processes) p->applyBatch(array, nx, ny, nz);
 }
 
+size_t sizeOfDataType(int dataType)
+{
+    switch (dataType) {
+    case FIMEX_AMD_CDM_CHAR: case FIMEX_AMD_CDM_UCHAR: return 1;
+    case FIMEX_AMD_CDM_SHORT: case FIMEX_AMD_CDM_USHORT: return 2;
+    case FIMEX_AMD_CDM_INT: case FIMEX_AMD_CDM_UINT: case FIMEX_AMD_CDM_FLOAT: return 4;
+    case FIMEX_AMD_CDM_DOUBLE: case FIMEX_AMD_CDM_INT64: case FIMEX_AMD_CDM_UINT64: return 8;
+    default: throw CDMException("cannot convert datatype " + std::to_string(dataType));  // src/DataImpl.h:343-345
+    }
+}
+
+// CDM::getFillValue without a _FillValue attribute: defaultFillValue_ (src/CDM.cc:490-505, include/fimex/CDMconstants.h:149-158)
+double defaultFillValue(int dataType)
+{
+    switch (dataType) {
+    case FIMEX_AMD_CDM_DOUBLE: return 9.9692099683868690e+36;
+    case FIMEX_AMD_CDM_FLOAT: return 9.9692099683868690e+36f;
+    case FIMEX_AMD_CDM_INT64: return (double)(-9223372036854775806LL);
+    case FIMEX_AMD_CDM_INT: return -2147483647.;
+    case FIMEX_AMD_CDM_SHORT: return -32767.;
+    case FIMEX_AMD_CDM_CHAR: return -127.;
+    case FIMEX_AMD_CDM_UINT64: return (double)18446744073709551614ULL;
+    case FIMEX_AMD_CDM_UINT: return 4294967295.;
+    case FIMEX_AMD_CDM_USHORT: return 65535.;
+    case FIMEX_AMD_CDM_UCHAR: return 255.;
+    default: return std::numeric_limits<double>::quiet_NaN();  // MIFI_UNDEFINED_D
+    }
+}
+
+// default for readers that only hold floats
+TypedData GridReader::getTypedDataSlice(const std::string& varName, size_t unLimDimPos, size_t x0, size_t nx, size_t y0, size_t ny)
+{
+    TypedData d;
+    d.dataType = FIMEX_AMD_CDM_FLOAT;
+    shared_array<float> f = getDataSlice(varName, unLimDimPos, x0, nx, y0, ny, d.size);
+    d.bytes = shared_array<unsigned char>(f, reinterpret_cast<unsigned char*>(f.get()));  // aliasing: shares ownership
+    return d;
+}
+
+TypedData CDMInterpolator::readTypedInput(const std::string& varName, size_t unLimDimPos) const
+{
+    const auto rd = cachedInterpolation_->reducedDomain();
+    const size_t x0 = rd ? rd->xMin : 0, y0 = rd ? rd->yMin : 0;
+    TypedData d = dataReader_->getTypedDataSlice(varName, unLimDimPos, x0, cachedInterpolation_->getInX(), y0, cachedInterpolation_->getInY());
+    if (d.dataType != dataReader_->variable(varName).dataType)
+        throw CDMException("reader delivered " + varName + " in type " + std::to_string(d.dataType));
+    return d;
+}
+
 // src/CDMInterpolator.cc:235-287
-shared_array<float> CDMInterpolator::getDataSlice(const std::string& varName, size_t unLimDimPos, size_t& size)
+TypedData CDMInterpolator::getTypedDataSlice(const std::string& varName, size_t unLimDimPos)
 {
     if (!dataReader_->hasVariable(varName)) throw CDMException("variable not found: " + varName);
     if (!cachedInterpolation_) throw CDMException("no cached interpolation for " + varName);  // :247-249
     const VariableInfo var = dataReader_->variable(varName);
-    size_t inSize = 0;
-    shared_array<float> data = readInput(varName, unLimDimPos, inSize);
-    size = 0;
-    if (inSize == 0) return data;  // :252-253
-    const float nan = std::numeric_limits<float>::quiet_NaN();
-    const float badValue = var.hasFillValue ? (float)var.fillValue : nan;
+    TypedData data = readTypedInput(varName, unLimDimPos);
+    if (data.size == 0) return data;  // :252-253
+    const double badValue = var.hasFillValue ? var.fillValue : defaultFillValue(var.dataType);  // CDM::getFillValue, :254
 
     const bool rotate = var.spatialVector &&
                         !(var.direction.find("x") == std::string::npos && var.direction.find("y") == std::string::npos);
-    shared_array<float> counterpart;
-    float badCounterpart = nan;
-    bool isX = true;
+    TypedData counterpart;
+    double badCounterpart = std::numeric_limits<double>::quiet_NaN();
+    bool isX = true, haveCounterpart = false;
     if (rotate) {
         if (cachedVectorReprojection_) {
-            size_t cSize = 0;
-            counterpart = readInput(var.counterpart, unLimDimPos, cSize);  // :269
+            counterpart = readTypedInput(var.counterpart, unLimDimPos);  // :269
+            haveCounterpart = true;
             const VariableInfo cv = dataReader_->variable(var.counterpart);
-            badCounterpart = cv.hasFillValue ? (float)cv.fillValue : nan;
+            badCounterpart = cv.hasFillValue ? cv.fillValue : defaultFillValue(cv.dataType);
             if (var.direction.find("x") != std::string::npos) isX = true;
             else if (var.direction.find("y") != std::string::npos) isX = false;
             else throw CDMException("could not find x,y direction for vector: " + varName + ", direction: " + var.direction);
@@ -176,40 +223,59 @@ shared_array<float> CDMInterpolator::getDataSlice(const std::string& varName, si
     bool builtin = true;
     for (size_t i = 0; i < pre.size(); ++i) builtin = preprocesses_[i]->describe(pre[i]) && builtin;
     for (size_t i = 0; i < post.size(); ++i) builtin = postprocesses_[i]->describe(post[i]) && builtin;
-    const auto* plan = dynamic_cast<const CachedInterpolation*>(cachedInterpolation_.get());
-    if (builtin && plan != nullptr) {
-        // the whole sequence :255-285 in one call, the slices resident in HBM between the steps
-        const fimex_amd_regrid_plan* h = plan->plan().get();
-        const fimex_amd_vector_plan* vec = counterpart ? cachedVectorReprojection_->handle() : nullptr;
-        const float* cp = vec ? counterpart.get() : nullptr;  // uninitialised reprojection = identity (:37-40)
-        checkAmd(fimex_amd_regrid_slice_host(h, data.get(), inSize, badValue, pre.data(), pre.size(), cp, badCounterpart, vec, isX,
-                                             post.data(), post.size(), nullptr, 0, &size),
+    const fimex_amd_regrid_plan* h = cachedInterpolation_->amdPlan();
+    TypedData out;
+    out.dataType = var.dataType;  // :285 variable.getDataType()
+    const size_t elem = sizeOfDataType(out.dataType);
+    if (builtin && h != nullptr) {
+        // the whole sequence :254-285 in one call, the slices resident in HBM between the steps
+        const fimex_amd_vector_plan* vec = haveCounterpart ? cachedVectorReprojection_->handle() : nullptr;
+        const void* cp = vec ? counterpart.bytes.get() : nullptr;  // uninitialised reprojection = identity (:37-40)
+        checkAmd(fimex_amd_regrid_slice_typed_host(h, data.bytes.get(), data.dataType, data.size, badValue, pre.data(), pre.size(), cp,
+                                                   counterpart.dataType, badCounterpart, vec, isX, post.data(), post.size(), nullptr, 0,
+                                                   &out.size),
                  "interpolateValues");
-        shared_array<float> out(new float[size ? size : 1]);
-        checkAmd(fimex_amd_regrid_slice_host(h, data.get(), inSize, badValue, pre.data(), pre.size(), cp, badCounterpart, vec, isX,
-                                             post.data(), post.size(), out.get(), size, &size),
+        out.bytes = shared_array<unsigned char>(new unsigned char[out.size ? out.size * elem : 1]);
+        checkAmd(fimex_amd_regrid_slice_typed_host(h, data.bytes.get(), data.dataType, data.size, badValue, pre.data(), pre.size(), cp,
+                                                   counterpart.dataType, badCounterpart, vec, isX, post.data(), post.size(),
+                                                   out.bytes.get(), out.size, &out.size),
                  "interpolateValues");
         return out;
     }
 
-    // general path (forward plans, user-defined processes): the reference's sequence call by call
-    if (var.hasFillValue)
-        for (size_t i = 0; i < inSize; ++i) if (data[i] == badValue) data[i] = nan;  // mifi_bad2nanf
-    processArray(preprocesses_, data.get(), inSize, cachedInterpolation_->getInX(), cachedInterpolation_->getInY());
-    shared_array<float> iArray = cachedInterpolation_->interpolateValues(data, inSize, size);
-    if (counterpart) {
-        if (!std::isnan(badCounterpart))
-            for (size_t i = 0; i < inSize; ++i) if (counterpart[i] == badCounterpart) counterpart[i] = nan;
-        processArray(preprocesses_, counterpart.get(), inSize, cachedInterpolation_->getInX(), cachedInterpolation_->getInY());
+    // general path (user-defined processes or interpolation objects): the reference's sequence call by call
+    auto toFloat = [&](const TypedData& d, double bad) {  // data2InterpolationArray, :115-119
+        shared_array<float> f(new float[d.size]);
+        checkAmd(fimex_amd_data2interpolation_host(d.bytes.get(), d.dataType, d.size, bad, f.get()), "data2InterpolationArray");
+        return f;
+    };
+    shared_array<float> array = toFloat(data, badValue);
+    processArray(preprocesses_, array.get(), data.size, cachedInterpolation_->getInX(), cachedInterpolation_->getInY());
+    size_t newSize = 0;
+    shared_array<float> iArray = cachedInterpolation_->interpolateValues(array, data.size, newSize);
+    if (haveCounterpart) {
+        shared_array<float> cArrayIn = toFloat(counterpart, badCounterpart);
+        processArray(preprocesses_, cArrayIn.get(), data.size, cachedInterpolation_->getInX(), cachedInterpolation_->getInY());
         size_t cs = 0;
-        shared_array<float> cArray = cachedInterpolation_->interpolateValues(counterpart, inSize, cs);
-        if (isX) cachedVectorReprojection_->reprojectValues(iArray, cArray, size);
-        else cachedVectorReprojection_->reprojectValues(cArray, iArray, size);
+        shared_array<float> cArray = cachedInterpolation_->interpolateValues(cArrayIn, data.size, cs);
+        if (isX) cachedVectorReprojection_->reprojectValues(iArray, cArray, newSize);
+        else cachedVectorReprojection_->reprojectValues(cArray, iArray, newSize);
     }
-    processArray(postprocesses_, iArray.get(), size, cachedInterpolation_->getOutX(), cachedInterpolation_->getOutY());
-    if (var.hasFillValue)
-        for (size_t i = 0; i < size; ++i) if (std::isnan(iArray[i])) iArray[i] = badValue;  // mifi_nanf2bad
-    return iArray;
+    processArray(postprocesses_, iArray.get(), newSize, cachedInterpolation_->getOutX(), cachedInterpolation_->getOutY());
+    out.size = newSize;
+    out.bytes = shared_array<unsigned char>(new unsigned char[newSize ? newSize * elem : 1]);
+    checkAmd(fimex_amd_interpolation2data_host(iArray.get(), newSize, out.dataType, badValue, out.bytes.get()), "interpolationArray2Data");  // :285
+    return out;
+}
+
+// float convenience form for float variables
+shared_array<float> CDMInterpolator::getDataSlice(const std::string& varName, size_t unLimDimPos, size_t& size)
+{
+    if (dataReader_->hasVariable(varName) && dataReader_->variable(varName).dataType != FIMEX_AMD_CDM_FLOAT)
+        throw CDMException("getDataSlice: " + varName + " is not stored as float, use getTypedDataSlice");
+    TypedData d = getTypedDataSlice(varName, unLimDimPos);
+    size = d.size;
+    return shared_array<float>(d.bytes, reinterpret_cast<float*>(d.bytes.get()));
 }
 
 }  // namespace FimexAmd

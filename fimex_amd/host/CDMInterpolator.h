@@ -18,12 +18,22 @@ namespace FimexAmd {
 struct VariableInfo {
     std::string name;
     size_t levels = 1;              // z slices per unlimited-dimension step
-    double fillValue = 0;           // used when hasFillValue
-    bool hasFillValue = false;
+    double fillValue = 0;           // _FillValue attribute, used when hasFillValue
+    bool hasFillValue = false;      // without the attribute the type's default fill value applies (src/CDM.cc:517-518)
     bool spatialVector = false;     // CDMVariable::isSpatialVector
     std::string counterpart;        // CDMVariable::getSpatialVectorCounterpart
     std::string direction;          // CDMVariable::getSpatialVectorDirection, contains "x" or "y"
+    int dataType = FIMEX_AMD_CDM_FLOAT;  // CDMVariable::getDataType (CDMDataType values)
 };
+
+// Data of one slice in the variable's stored type (the reference's DataPtr, reduced to what this path needs)
+struct TypedData {
+    int dataType = FIMEX_AMD_CDM_FLOAT;
+    size_t size = 0;                     // elements
+    shared_array<unsigned char> bytes;   // size * sizeOfDataType(dataType) bytes
+};
+size_t sizeOfDataType(int dataType);     // throws CDMException for CDM_NAT / CDM_STRING
+double defaultFillValue(int dataType);   // CDM::getFillValue of a variable without _FillValue (src/CDM.cc:490-505)
 
 // the upstream reader as seen by this path: one horizontal grid with a projection, float slices
 class GridReader {
@@ -40,6 +50,8 @@ public:
     // (CachedInterpolationInterface::getInputDataSlice with a reduced domain, src/CachedInterpolation.cc:44-65)
     virtual shared_array<float> getDataSlice(const std::string& varName, size_t unLimDimPos, size_t x0, size_t nx, size_t y0,
                                              size_t ny, size_t& size) = 0;
+    // the same slice in the variable's stored type (VariableInfo::dataType); readers of float data need not override
+    virtual TypedData getTypedDataSlice(const std::string& varName, size_t unLimDimPos, size_t x0, size_t nx, size_t y0, size_t ny);
     // forward interpolation: longitude / latitude in degrees of every source cell, [ny][nx]; false when unavailable
     virtual bool lonLat(std::vector<double>& lon, std::vector<double>& lat) const { (void)lon; (void)lat; return false; }
 };
@@ -56,6 +68,9 @@ public:
 
     // src/CDMInterpolator.cc:235-287; returns [levels][outY][outX] floats with the variable's fill value restored
     shared_array<float> getDataSlice(const std::string& varName, size_t unLimDimPos, size_t& size);
+    // the same on the variable's stored type, as the reference's DataPtr-returning getDataSlice: data2InterpolationArray
+    // (:115-119) and interpolationArray2Data (:121-124) included, only typed elements cross PCIe
+    TypedData getTypedDataSlice(const std::string& varName, size_t unLimDimPos);
 
     void addPreprocess(std::shared_ptr<InterpolatorProcess2d> process) { preprocesses_.push_back(process); }
     void addPostprocess(std::shared_ptr<InterpolatorProcess2d> process) { postprocesses_.push_back(process); }
@@ -79,6 +94,7 @@ private:
     void changeProjectionByForwardInterpolation(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                 std::vector<double> outYAxis, bool xDegree, bool yDegree);
     shared_array<float> readInput(const std::string& varName, size_t unLimDimPos, size_t& size) const;
+    TypedData readTypedInput(const std::string& varName, size_t unLimDimPos) const;
     void processArray(const std::vector<std::shared_ptr<InterpolatorProcess2d>>& processes, float* array, size_t size, size_t nx, size_t ny) const;
 };
 

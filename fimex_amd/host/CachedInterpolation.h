@@ -58,6 +58,8 @@ public:
     virtual size_t getOutX() const = 0;
     virtual size_t getOutY() const = 0;
     virtual std::shared_ptr<ReducedInterpolationDomain> reducedDomain() const { return std::shared_ptr<ReducedInterpolationDomain>(); }
+    // the engine's plan behind this object, NULL for implementations that are not backed by libfimex_amd
+    virtual const fimex_amd_regrid_plan* amdPlan() const { return nullptr; }
     const std::string& xDimName() const { return xDimName_; }
     const std::string& yDimName() const { return yDimName_; }
 
@@ -96,6 +98,7 @@ public:
     // src/CachedInterpolation.cc:159-200; run immediately after construction
     void createReducedDomain(std::string xDimName, std::string yDimName);
     const PlanHolder& plan() const { return plan_; }
+    const fimex_amd_regrid_plan* amdPlan() const override { return plan_.get(); }
 
 private:
     std::vector<double> pointsOnXAxis, pointsOnYAxis;
@@ -116,6 +119,7 @@ public:
     size_t getInY() const override { return inY; }
     size_t getOutX() const override { return outX; }
     size_t getOutY() const override { return outY; }
+    const fimex_amd_regrid_plan* amdPlan() const override { return plan_.get(); }
 
 private:
     size_t inX, inY, outX, outY;

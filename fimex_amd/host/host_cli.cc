@@ -5,14 +5,16 @@
 // spec.txt (one item per line):
 //   proj <proj4 string of the source grid>
 //   xaxis <file of doubles>      yaxis <file of doubles>
-//   var <name> <levels> <file of floats [steps][levels][ny][nx]> <fill|nan> [vector <counterpart> <x|y>]
+//   var <name> <levels> <file [steps][levels][ny][nx]> <fill|nan> [vector <counterpart> <x|y>] [type <char|short|int|float|double|uchar|ushort|uint|int64|uint64>]
+//       (the file holds elements of that type, float by default)
 //   method <name>                 outproj <proj4>
 //   outx <file of doubles> <unit> outy <file of doubles> <unit>
 //   pre|post fill2d <relaxCrit> <corrEff> <maxLoop> | creepfill2d <repeat> <weight> | creepfillval2d <repeat> <weight> <default>
-//   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32)
+//   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32 for float variables, .raw in the stored type otherwise)
 // Also writes <out_dir>/points_x.f64, points_y.f64 (plan positions) and matrix.f64 (rotation matrix, if any).
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <limits>
@@ -47,24 +49,32 @@ public:
     std::string proj;
     std::vector<double> x, y;
     std::map<std::string, VariableInfo> vars;
-    std::map<std::string, std::vector<float>> data;
+    std::map<std::string, std::vector<unsigned char>> data;  // raw elements of the variable's type
     std::string projString() const override { return proj; }
     std::vector<double> xAxis() const override { return x; }
     std::vector<double> yAxis() const override { return y; }
     bool hasVariable(const std::string& n) const override { return vars.count(n) != 0; }
     VariableInfo variable(const std::string& n) const override { return vars.at(n); }
-    shared_array<float> getDataSlice(const std::string& n, size_t step, size_t x0, size_t nx, size_t y0, size_t ny, size_t& size) override
+    TypedData getTypedDataSlice(const std::string& n, size_t step, size_t x0, size_t nx, size_t y0, size_t ny) override
     {
         const VariableInfo& v = vars.at(n);
-        const std::vector<float>& d = data.at(n);
-        const size_t NX = x.size(), NY = y.size();
-        size = v.levels * nx * ny;
-        shared_array<float> out(new float[size ? size : 1]);
+        const std::vector<unsigned char>& d = data.at(n);
+        const size_t NX = x.size(), NY = y.size(), e = sizeOfDataType(v.dataType);
+        TypedData out;
+        out.dataType = v.dataType;
+        out.size = v.levels * nx * ny;
+        out.bytes = shared_array<unsigned char>(new unsigned char[out.size ? out.size * e : 1]);
         for (size_t l = 0; l < v.levels; ++l)
             for (size_t j = 0; j < ny; ++j)
-                for (size_t i = 0; i < nx; ++i)
-                    out[(l * ny + j) * nx + i] = d[((step * v.levels + l) * NY + y0 + j) * NX + x0 + i];
+                std::memcpy(out.bytes.get() + ((l * ny + j) * nx) * e, d.data() + (((step * v.levels + l) * NY + y0 + j) * NX + x0) * e, nx * e);
         return out;
+    }
+    shared_array<float> getDataSlice(const std::string& n, size_t step, size_t x0, size_t nx, size_t y0, size_t ny, size_t& size) override
+    {
+        if (vars.at(n).dataType != FIMEX_AMD_CDM_FLOAT) throw CDMException(n + " is not stored as float");
+        TypedData d = getTypedDataSlice(n, step, x0, nx, y0, ny);
+        size = d.size;
+        return shared_array<float>(d.bytes, reinterpret_cast<float*>(d.bytes.get()));
     }
 };
 
@@ -135,9 +145,21 @@ int main(int argc, char** argv)
                 std::string file, fill, kw;
                 in >> v.name >> v.levels >> file >> fill;
                 if (fill != "nan") { v.hasFillValue = true; v.fillValue = std::stod(fill); }
-                if (in >> kw && kw == "vector") { v.spatialVector = true; in >> v.counterpart >> v.direction; }
+                while (in >> kw) {
+                    if (kw == "vector") { v.spatialVector = true; in >> v.counterpart >> v.direction; }
+                    else if (kw == "type") {
+                        std::string t;
+                        in >> t;
+                        static const std::map<std::string, int> types = {
+                            {"char", FIMEX_AMD_CDM_CHAR}, {"short", FIMEX_AMD_CDM_SHORT}, {"int", FIMEX_AMD_CDM_INT}, {"float", FIMEX_AMD_CDM_FLOAT},
+                            {"double", FIMEX_AMD_CDM_DOUBLE}, {"uchar", FIMEX_AMD_CDM_UCHAR}, {"ushort", FIMEX_AMD_CDM_USHORT},
+                            {"uint", FIMEX_AMD_CDM_UINT}, {"int64", FIMEX_AMD_CDM_INT64}, {"uint64", FIMEX_AMD_CDM_UINT64}};
+                        if (!types.count(t)) throw CDMException("unknown type " + t);
+                        v.dataType = types.at(t);
+                    }
+                }
                 reader->vars[v.name] = v;
-                reader->data[v.name] = readAll<float>(file);
+                reader->data[v.name] = readAll<unsigned char>(file);
             } else if (key == "pre" || key == "post") {
                 std::string kind;
                 in >> kind;
@@ -162,9 +184,10 @@ int main(int argc, char** argv)
         if (auto rd = ci->reducedDomain()) std::cout << " reduced xMin " << rd->xMin << " yMin " << rd->yMin;
         std::cout << std::endl;
         for (auto& g : gets) {
-            size_t size = 0;
-            shared_array<float> out = interp.getDataSlice(g.first, g.second, size);
-            writeAll(outDir + "/" + g.first + "_" + std::to_string(g.second) + ".f32", out.get(), size);
+            const TypedData out = interp.getTypedDataSlice(g.first, g.second);
+            const bool isFloat = out.dataType == FIMEX_AMD_CDM_FLOAT;
+            writeAll(outDir + "/" + g.first + "_" + std::to_string(g.second) + (isFloat ? ".f32" : ".raw"), out.bytes.get(),
+                     out.size * sizeOfDataType(out.dataType));
         }
         return 0;
     } catch (const std::exception& e) {

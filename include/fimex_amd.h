@@ -231,6 +231,10 @@ int fimex_amd_data2interpolation_device(const void* d_in, int cdmType, size_t n,
  *  DataImpl<float>::convertDataType(MIFI_UNDEFINED_F, 1, 0, cdmType, badValue, 1, 0) does (NaN -> fill value,
  *  integers rounded through MetNoFimex::round), in one pass. */
 int fimex_amd_interpolation2data_device(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, void* stream);
+/** The same two conversions on host buffers (copied to the GPU and back), for callers that run their own 2-D processes
+ *  on the float array in between. */
+int fimex_amd_data2interpolation_host(const void* in, int cdmType, size_t n, double badValue, float* out);
+int fimex_amd_interpolation2data_host(const float* in, size_t n, int cdmType, double badValue, void* out);
 /** fimex_amd_regrid_slice_host on the variable's stored type: everything CDMInterpolator::getDataSlice
  *  (src/CDMInterpolator.cc:251-285) does with a slice, including both conversions; only `size` elements of dataType
  *  cross PCIe in, *newSize elements of dataType come back (half the bytes for packed shorts).  size and outCapacity

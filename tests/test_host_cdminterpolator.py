@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "fimex_amd", "host_cli.so")
 GEO = "+proj=latlong +R=6371000"
+FILL_FLOAT = 9.9692099683868690e+36  # MIFI_FILL_FLOAT: CDM::getFillValue of a float variable without _FillValue (src/CDM.cc:490-518)
 
 
 def _run(tmp, spec_lines):
@@ -80,12 +81,14 @@ def test_coordtest_to_latlon_200x200(tmp_path, coordtest, method, code):
     np.testing.assert_allclose(py, wy, atol=1e-7)
     assert (px < -0.5).any() and (px > 10.5).any()  # the target overshoots the 11x11 source
 
-    def regrid(name, step):
-        f = oracle.bad2nan(ct[name][step], ct[name + "_fill"]) if ct[name + "_fill"] is not None else ct[name][step]
-        return oracle.interpolate_values(code, px, py, f, 11, 11, 200, 200)
+    def fill_of(name):
+        return FILL_FLOAT if ct[name + "_fill"] is None else float(ct[name + "_fill"])
 
-    def back(a, name):
-        return oracle.nan2bad(a, ct[name + "_fill"]) if ct[name + "_fill"] is not None else a
+    def regrid(name, step):
+        return oracle.interpolate_values(code, px, py, oracle.bad2nan(ct[name][step], fill_of(name)), 11, 11, 200, 200)
+
+    def back(a, name):  # interpolationArray2Data for a float variable
+        return oracle.interpolation_array2data(a, oracle.CDM_FLOAT, fill_of(name))
 
     for name, step in (("air_temperature", 0), ("air_temperature", 3), ("cloud_area_fraction_in_atmosphere_layer", 1)):
         got = np.fromfile(out / ("%s_%d.f32" % (name, step)), dtype=np.float32).reshape(-1, 200, 200)
@@ -126,7 +129,7 @@ def test_coordtest_with_pre_and_postprocess(tmp_path, coordtest):
     f = np.stack([oracle.creepfill2d(s, 5, 2)[0] for s in f])
     r = oracle.interpolate_values(oracle.BILINEAR, px, py, f, 11, 11, 200, 200)
     r = np.stack([oracle.fill2d(s, 4.0, 1.6, 100)[0] for s in r])
-    want = oracle.nan2bad(r, ct["air_temperature_fill"])
+    want = oracle.interpolation_array2data(r, oracle.CDM_FLOAT, float(ct["air_temperature_fill"]))
     got = np.fromfile(out / "air_temperature_1.f32", dtype=np.float32).reshape(-1, 200, 200)
     assert not np.isnan(got).any() and not (got == ct["air_temperature_fill"]).any()  # fill2d closed the outside too
     assert cases.same(got, want), cases.describe_mismatch(got, want)
@@ -154,6 +157,43 @@ def test_forward_interpolation_latlon_to_lambert(tmp_path, method, code):
     np.testing.assert_allclose(px, oracle.points2position(wx, ox), atol=1e-6)
     np.testing.assert_allclose(py, oracle.points2position(wy, oy), atol=1e-6)
     want = oracle.forward_interpolate_values(code, px, py, f[1], lon.size, lat.size, 40, 30)
+    assert np.isnan(want).any() and np.isfinite(want).mean() > 0.5
+    want = oracle.interpolation_array2data(want, oracle.CDM_FLOAT, FILL_FLOAT)  # no _FillValue: the type's default fill value
     got = np.fromfile(out / "field_1.f32", dtype=np.float32).reshape(3, 30, 40)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
-    assert np.isfinite(got).mean() > 0.5
+
+
+def test_coordtest_packed_shorts_stay_shorts(tmp_path, golden_dir):
+    """The stored type end to end: coordTest.nc's short variables go to the GPU as shorts, become float/NaN there
+    (data2InterpolationArray), are regridded and come back as shorts (interpolationArray2Data: NaN -> _FillValue or the
+    type's default fill value, values rounded half away from zero)."""
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "coordTest.nc"), "r", mmap=False) as f:
+        v = f.variables
+        x, y = v["x"].data.astype(np.float64), v["y"].data.astype(np.float64)
+        proj = v["projection_1"].proj4.decode()
+        raw = {n: np.ascontiguousarray(v[n].data.astype(np.int16)).reshape(4, -1, 11, 11)
+               for n in ("air_temperature", "sea_surface_temperature", "altitude")}
+        fills = {n: (float(v[n]._FillValue) if hasattr(v[n], "_FillValue") else None) for n in raw}
+    assert fills["sea_surface_temperature"] is None and fills["air_temperature"] == -32767.0
+    x.tofile(tmp_path / "x.f64"); y.tofile(tmp_path / "y.f64")
+    lon = np.linspace(-15.2, -9.7, 200); lat = np.linspace(28.3, 33.0, 200)
+    lon.tofile(tmp_path / "ox.f64"); lat.tofile(tmp_path / "oy.f64")
+    lines = ["proj " + proj, "xaxis %s" % (tmp_path / "x.f64"), "yaxis %s" % (tmp_path / "y.f64"), "method bilinear", "outproj " + GEO,
+             "outx %s degrees_east" % (tmp_path / "ox.f64"), "outy %s degrees_north" % (tmp_path / "oy.f64"), "post creepfill2d 3 1"]
+    for n, a in raw.items():
+        a.tofile(tmp_path / (n + ".i16"))
+        lines.append("var %s %d %s %s type short" % (n, a.shape[1], tmp_path / (n + ".i16"), "nan" if fills[n] is None else repr(fills[n])))
+        lines.append("get %s 2" % n)
+    out, _ = _run(tmp_path, lines)
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    for n, a in raw.items():
+        bad = -32767.0 if fills[n] is None else fills[n]  # MIFI_FILL_SHORT
+        f = oracle.data2interpolation_array(a[2], bad)
+        r = oracle.interpolate_values(oracle.BILINEAR, px, py, f, 11, 11, 200, 200)
+        r = np.stack([oracle.creepfill2d(s, 3, 1)[0] for s in r])
+        want = oracle.interpolation_array2data(r, oracle.CDM_SHORT, bad)
+        got = np.fromfile(out / ("%s_2.raw" % n), dtype=np.int16).reshape(want.shape)
+        assert np.array_equal(got, want), n
+        if n == "air_temperature":
+            assert (got != np.int16(bad)).mean() > 0.1 and (a[2] != np.int16(bad)).all()

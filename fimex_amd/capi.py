@@ -84,6 +84,13 @@ SYMBOLS = {
     "fimex_amd_regrid_slice_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, _Z, ctypes.c_double, ctypes.POINTER(Process2d), _Z,
                                                          _V, ctypes.c_int, ctypes.c_double, _V, ctypes.c_int,
                                                          ctypes.POINTER(Process2d), _Z, _V, _Z, _ZP]),
+    "fimex_amd_project_values_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z]),
+    "fimex_amd_project_values_device": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _V, _V, _Z, _V]),
+    "fimex_amd_project_axes_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z, _Z, _D, _D]),
+    "fimex_amd_project_axes_device": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z, _Z, _V, _V, _V]),
+    "fimex_amd_get_vector_reproject_matrix_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, ctypes.c_int, ctypes.c_int, _Z, _Z, _D]),
+    "fimex_amd_get_vector_reproject_matrix_device": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, ctypes.c_int, ctypes.c_int, _Z, _Z, _V, _V]),
+    "fimex_amd_projection_is_degree": (ctypes.c_int, [ctypes.c_char_p]),
     "fimex_amd_scan_sum_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _ZP, _V]),
 }
 
@@ -345,6 +352,49 @@ def bad2nan_device(d_data, n, bad, stream=0):
 
 def nan2bad_device(d_data, n, bad, stream=0):
     _check(load().fimex_amd_nan2bad_device(d_data, n, bad, stream))
+
+
+def project_values_host(proj_input, proj_output, x, y):
+    """mifi_project_values: returns the transformed copies of x and y."""
+    xs, ys = _f64(x).copy(), _f64(y).copy()
+    fx, fy = xs.reshape(-1), ys.reshape(-1)
+    _check(load().fimex_amd_project_values_host(proj_input.encode(), proj_output.encode(), _dp(fx), _dp(fy), fx.size))
+    return xs, ys
+
+
+def project_axes_host(proj_input, proj_output, xAxis, yAxis):
+    """mifi_project_axes: two [iy][ix] fields."""
+    ax, ay = _f64(xAxis).ravel(), _f64(yAxis).ravel()
+    ox, oy = np.empty(ax.size * ay.size), np.empty(ax.size * ay.size)
+    _check(load().fimex_amd_project_axes_host(proj_input.encode(), proj_output.encode(), _dp(ax), _dp(ay), ax.size, ay.size, _dp(ox), _dp(oy)))
+    return ox.reshape(ay.size, ax.size), oy.reshape(ay.size, ax.size)
+
+
+def project_axes_device(proj_input, proj_output, xAxis, yAxis, d_outX, d_outY, stream=0):
+    ax, ay = _f64(xAxis).ravel(), _f64(yAxis).ravel()
+    _check(load().fimex_amd_project_axes_device(proj_input.encode(), proj_output.encode(), _dp(ax), _dp(ay), ax.size, ay.size, d_outX, d_outY, stream))
+
+
+def get_vector_reproject_matrix_host(proj_input, proj_output, outXAxis, outYAxis, xAxisType=PROJ_AXIS, yAxisType=PROJ_AXIS):
+    """mifi_get_vector_reproject_matrix: float64 [oy*ox*4]."""
+    ax, ay = _f64(outXAxis).ravel(), _f64(outYAxis).ravel()
+    m = np.empty(4 * ax.size * ay.size)
+    _check(load().fimex_amd_get_vector_reproject_matrix_host(proj_input.encode(), proj_output.encode(), _dp(ax), _dp(ay), xAxisType, yAxisType,
+                                                             ax.size, ay.size, _dp(m)))
+    return m
+
+
+def get_vector_reproject_matrix_device(proj_input, proj_output, outXAxis, outYAxis, xAxisType, yAxisType, d_matrix, stream=0):
+    ax, ay = _f64(outXAxis).ravel(), _f64(outYAxis).ravel()
+    _check(load().fimex_amd_get_vector_reproject_matrix_device(proj_input.encode(), proj_output.encode(), _dp(ax), _dp(ay), xAxisType, yAxisType,
+                                                               ax.size, ay.size, d_matrix, stream))
+
+
+def projection_is_degree(proj):
+    r = load().fimex_amd_projection_is_degree(proj.encode())
+    if r < 0:
+        raise FimexAmdError(load().fimex_amd_last_error().decode() or "fimex_amd call failed")
+    return bool(r)
 
 
 def scan_sum_device(d_values, n, mode=0, average=0.0, algo=1, stream=0):

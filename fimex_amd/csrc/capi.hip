@@ -593,6 +593,96 @@ int fimex_amd_points2position_host(double* points, size_t n, const double* axis,
     });
 }
 
+int fimex_amd_project_values_device(const char* proj_input, const char* proj_output, double* d_x, double* d_y, size_t num, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(num == 0 || (d_x != nullptr && d_y != nullptr), "NULL device buffer");
+        (void)current_device_checked();
+        launch_project_values(proj_input, proj_output, d_x, d_y, num, as_stream(stream));
+    });
+}
+
+int fimex_amd_project_values_host(const char* proj_input, const char* proj_output, double* x, double* y, size_t num)
+{
+    return c_guard([&] {
+        FA_REQUIRE(num == 0 || (x != nullptr && y != nullptr), "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(2 * num);
+        if (num) {
+            FA_HIP(hipMemcpyAsync(d.get(), x, num * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+            FA_HIP(hipMemcpyAsync(d.get() + num, y, num * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        }
+        launch_project_values(proj_input, proj_output, d.get(), d.get() + num, num, stream.get());
+        if (num) {
+            FA_HIP(hipMemcpyAsync(x, d.get(), num * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+            FA_HIP(hipMemcpyAsync(y, d.get() + num, num * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+        }
+        stream.sync();
+    });
+}
+
+int fimex_amd_project_axes_device(const char* proj_input, const char* proj_output, const double* in_x_axis, const double* in_y_axis,
+                                  size_t ix, size_t iy, double* d_outX, double* d_outY, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(ix * iy == 0 || (in_x_axis != nullptr && in_y_axis != nullptr && d_outX != nullptr && d_outY != nullptr), "NULL argument");
+        (void)current_device_checked();
+        launch_project_axes(proj_input, proj_output, in_x_axis, in_y_axis, ix, iy, d_outX, d_outY, as_stream(stream));
+    });
+}
+
+int fimex_amd_project_axes_host(const char* proj_input, const char* proj_output, const double* in_x_axis, const double* in_y_axis,
+                                size_t ix, size_t iy, double* outX, double* outY)
+{
+    return c_guard([&] {
+        const size_t n = ix * iy;
+        FA_REQUIRE(n == 0 || (in_x_axis != nullptr && in_y_axis != nullptr && outX != nullptr && outY != nullptr), "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(2 * n);
+        launch_project_axes(proj_input, proj_output, in_x_axis, in_y_axis, ix, iy, d.get(), d.get() + n, stream.get());
+        if (n) {
+            FA_HIP(hipMemcpyAsync(outX, d.get(), n * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+            FA_HIP(hipMemcpyAsync(outY, d.get() + n, n * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+        }
+        stream.sync();
+    });
+}
+
+int fimex_amd_get_vector_reproject_matrix_device(const char* proj_input, const char* proj_output, const double* out_x_axis,
+                                                 const double* out_y_axis, int xType, int yType, size_t ox, size_t oy,
+                                                 double* d_matrix, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(ox * oy == 0 || (out_x_axis != nullptr && out_y_axis != nullptr && d_matrix != nullptr), "NULL argument");
+        (void)current_device_checked();
+        launch_vector_reproject_matrix(proj_input, proj_output, out_x_axis, out_y_axis, xType, yType, ox, oy, d_matrix, as_stream(stream));
+    });
+}
+
+int fimex_amd_get_vector_reproject_matrix_host(const char* proj_input, const char* proj_output, const double* out_x_axis,
+                                               const double* out_y_axis, int xType, int yType, size_t ox, size_t oy, double* matrix)
+{
+    return c_guard([&] {
+        const size_t n = ox * oy;
+        FA_REQUIRE(n == 0 || (out_x_axis != nullptr && out_y_axis != nullptr && matrix != nullptr), "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(4 * n);
+        launch_vector_reproject_matrix(proj_input, proj_output, out_x_axis, out_y_axis, xType, yType, ox, oy, d.get(), stream.get());
+        if (n) FA_HIP(hipMemcpyAsync(matrix, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_projection_is_degree(const char* proj)
+{
+    int r = -1;
+    const int rc = c_guard([&] { r = projection_is_degree(proj); });
+    return rc == FIMEX_AMD_OK ? r : -1;
+}
+
 int fimex_amd_scan_sum_device(const float* d_values, size_t n, int mode, double average, int algo, double* sum, size_t* nUndefined, void* stream)
 {
     return c_guard([&] {

@@ -99,6 +99,14 @@ size_t cdm_type_size(int cdmType);  // throws for types without a float form
 void launch_data2interpolation(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, hipStream_t stream);
 void launch_interpolation2data(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, hipStream_t stream);
 
+// projection.hip: pj_transform-level plan building on the device
+void launch_project_values(const char* projIn, const char* projOut, double* d_x, double* d_y, size_t n, hipStream_t stream);
+void launch_project_axes(const char* projIn, const char* projOut, const double* h_xAxis, const double* h_yAxis, size_t ix, size_t iy,
+                         double* d_outX, double* d_outY, hipStream_t stream);
+void launch_vector_reproject_matrix(const char* projIn, const char* projOut, const double* h_outXAxis, const double* h_outYAxis,
+                                    int xAxisType, int yAxisType, size_t ox, size_t oy, double* d_matrix, hipStream_t stream);
+int projection_is_degree(const char* proj);
+
 // fill.hip
 void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
                 size_t* h_nChanged, hipStream_t stream);

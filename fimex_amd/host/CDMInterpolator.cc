@@ -18,6 +18,23 @@ void toRad(std::vector<double>& v)
     for (double& d : v) d *= DEG_TO_RAD;
 }
 
+// mifi_project_axes / mifi_project_values / mifi_get_vector_reproject_matrix on the GPU
+void projectAxesAmd(const std::string& from, const std::string& to, const std::vector<double>& xAxis, const std::vector<double>& yAxis,
+                    std::vector<double>& outX, std::vector<double>& outY)
+{
+    outX.resize(xAxis.size() * yAxis.size());
+    outY.resize(outX.size());
+    checkAmd(fimex_amd_project_axes_host(from.c_str(), to.c_str(), xAxis.data(), yAxis.data(), xAxis.size(), yAxis.size(), outX.data(), outY.data()),
+             ("unable to project axes from " + from + " to " + to).c_str());
+}
+
+bool isDegreeProjection(const std::string& proj)
+{
+    const int r = fimex_amd_projection_is_degree(proj.c_str());
+    if (r < 0) throw CDMException(std::string("projection: ") + fimex_amd_last_error());
+    return r != 0;
+}
+
 void points2position(std::vector<double>& points, const std::vector<double>& axis, int axisType)
 {
     checkAmd(fimex_amd_points2position_host(points.data(), points.size(), axis.data(), (int)axis.size(), axisType),
@@ -58,18 +75,17 @@ void CDMInterpolator::changeProjection(int method, const std::string& proj_input
 void CDMInterpolator::changeProjectionByProjectionParameters(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                              std::vector<double> outYAxis, bool xDegree, bool yDegree)
 {
-    const Projection outProj(proj_input), orgProj(dataReader_->projString());
+    const std::string orgProjStr = dataReader_->projString();
     const std::vector<double> outXAxisOrg = outXAxis, outYAxisOrg = outYAxis;
     int outXAxisType = MIFI_PROJ_AXIS, outYAxisType = MIFI_PROJ_AXIS;
     if (xDegree) { toRad(outXAxis); outXAxisType = MIFI_LONGITUDE; }
     if (yDegree) { toRad(outYAxis); outYAxisType = MIFI_LATITUDE; }
-    (void)outXAxisType; (void)outYAxisType;
 
     // positions of the new grid's cells in the original projection (:1458), then on the original axes (:1475-1476)
-    projectAxes(outProj, orgProj, outXAxis, outYAxis, pointsOnXAxis_, pointsOnYAxis_);
+    projectAxesAmd(proj_input, orgProjStr, outXAxis, outYAxis, pointsOnXAxis_, pointsOnYAxis_);
     std::vector<double> orgX = dataReader_->xAxis(), orgY = dataReader_->yAxis();
     int miupXAxis = MIFI_PROJ_AXIS, miupYAxis = MIFI_PROJ_AXIS;
-    if (orgProj.isDegree()) {
+    if (isDegreeProjection(orgProjStr)) {
         miupXAxis = MIFI_LONGITUDE;
         miupYAxis = MIFI_LATITUDE;
         toRad(orgX);
@@ -84,7 +100,10 @@ void CDMInterpolator::changeProjectionByProjectionParameters(int method, const s
     cachedInterpolation_ = ci;
 
     // rotation of x/y vector components (:1491-1500); the reference only builds it when the file holds such vectors
-    vectorReprojectMatrix(orgProj, outProj, outXAxis, outYAxis, matrix_);
+    matrix_.resize(4 * outXAxis.size() * outYAxis.size());
+    checkAmd(fimex_amd_get_vector_reproject_matrix_host(orgProjStr.c_str(), proj_input.c_str(), outXAxisOrg.data(), outYAxisOrg.data(),
+                                                        outXAxisType, outYAxisType, outXAxis.size(), outYAxis.size(), matrix_.data()),
+             "mifi_get_vector_reproject_matrix");  // :1497
     shared_array<double> m(new double[matrix_.size()]);
     std::copy(matrix_.begin(), matrix_.end(), m.get());
     cachedVectorReprojection_ =
@@ -99,11 +118,10 @@ void CDMInterpolator::changeProjectionByForwardInterpolation(int method, const s
     std::vector<double> orgX = dataReader_->xAxis(), orgY = dataReader_->yAxis();
     if (!dataReader_->lonLat(lonVals, latVals)) {
         // geographic grid: the matrix of its two axes (lonLatVals2Matrix, :1285-1289); otherwise project the grid
-        const Projection orgProj(dataReader_->projString());
+        const std::string orgProjStr = dataReader_->projString();
         std::vector<double> ax = orgX, ay = orgY;
-        if (orgProj.isDegree()) { toRad(ax); toRad(ay); }
-        const Projection geo(LAT_LON_PROJSTR);
-        projectAxes(orgProj, geo, ax, ay, lonVals, latVals);  // radians
+        if (isDegreeProjection(orgProjStr)) { toRad(ax); toRad(ay); }
+        projectAxesAmd(orgProjStr, LAT_LON_PROJSTR, ax, ay, lonVals, latVals);  // radians
     } else {
         toRad(lonVals);
         toRad(latVals);
@@ -112,8 +130,8 @@ void CDMInterpolator::changeProjectionByForwardInterpolation(int method, const s
     if (xDegree) { toRad(outXAxis); miupXAxis = MIFI_LONGITUDE; }
     if (yDegree) { toRad(outYAxis); miupYAxis = MIFI_LATITUDE; }
     // all input points in output coordinates (:1311), then cell positions on the output axes (:1316-1317)
-    const Projection geo(LAT_LON_PROJSTR), outProj(proj_input);
-    transform(geo, outProj, lonVals.data(), latVals.data(), lonVals.size());
+    checkAmd(fimex_amd_project_values_host(LAT_LON_PROJSTR.c_str(), proj_input.c_str(), lonVals.data(), latVals.data(), lonVals.size()),
+             ("unable to project values from " + LAT_LON_PROJSTR + " to " + proj_input).c_str());
     points2position(lonVals, outXAxis, miupXAxis);
     points2position(latVals, outYAxis, miupYAxis);
     pointsOnXAxis_ = lonVals;

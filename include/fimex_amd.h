@@ -253,6 +253,31 @@ int fimex_amd_points2position_device(double* d_points, size_t n, const double* a
 /** Same on n host doubles (copied to the GPU and back). */
 int fimex_amd_points2position_host(double* points, size_t n, const double* axis, int num, int axis_type);
 
+/* ----------------------------------- plan building across projections (8f n2) */
+/* The reference calls PROJ.4 (pj_init_plus / pj_transform) here; this library carries its own spherical projections:
+ * latlong/longlat, stere, lcc, merc, ob_tran with o_proj=longlat (radians at this boundary for geographic and rotated
+ * coordinates, as PROJ.4's legacy API).  Ellipsoidal or other strings make the call fail with a message. */
+/** mifi_project_values, include/fimex/interpolation.h / src/interpolation.c:1158-1197: n points in place. */
+int fimex_amd_project_values_host(const char* proj_input, const char* proj_output, double* in_out_x_vals, double* in_out_y_vals, size_t num);
+int fimex_amd_project_values_device(const char* proj_input, const char* proj_output, double* d_x_vals, double* d_y_vals, size_t num, void* stream);
+/** mifi_project_axes, src/interpolation.c:1199-1244: the [iy][ix] mesh of two host axes, transformed; the device form
+ *  leaves the two fields in device memory (feed fimex_amd_points2position_device / fimex_amd_regrid_plan_create_device). */
+int fimex_amd_project_axes_host(const char* proj_input, const char* proj_output, const double* in_x_axis, const double* in_y_axis,
+                                size_t ix, size_t iy, double* out_xproj_axis, double* out_yproj_axis);
+int fimex_amd_project_axes_device(const char* proj_input, const char* proj_output, const double* in_x_axis, const double* in_y_axis,
+                                  size_t ix, size_t iy, double* d_out_xproj_axis, double* d_out_yproj_axis, void* stream);
+/** mifi_get_vector_reproject_matrix, src/interpolation.c:719-788: matrix[4*ox*oy] = (cos, sin, -sin, phi) of the local
+ *  rotation from proj_input to proj_output on the mesh of the output axes (degrees for FIMEX_AMD_LONGITUDE /
+ *  FIMEX_AMD_LATITUDE axis types, as the reference).  Host or device destination. */
+int fimex_amd_get_vector_reproject_matrix_host(const char* proj_input, const char* proj_output, const double* out_x_axis,
+                                               const double* out_y_axis, int out_x_axis_type, int out_y_axis_type,
+                                               size_t ox, size_t oy, double* matrix);
+int fimex_amd_get_vector_reproject_matrix_device(const char* proj_input, const char* proj_output, const double* out_x_axis,
+                                                 const double* out_y_axis, int out_x_axis_type, int out_y_axis_type,
+                                                 size_t ox, size_t oy, double* d_matrix, void* stream);
+/** Projection::isDegree (src/coordSys/Projection.cc): 1 for geographic and rotated lat/lon strings, 0 otherwise, -1 on error. */
+int fimex_amd_projection_is_degree(const char* proj);
+
 /* ------------------------------------------------------------- diagnostics */
 /** The scan-order double sums the fills start with (src/interpolation.c:1256-1264 sum of the defined values, mode 0;
  *  :1288-1299 sum of |v - average|, mode 1; mode 2 only counts), on n device floats: exactly the value the reference's

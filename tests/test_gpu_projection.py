@@ -1,0 +1,152 @@
+"""Plan building across projections on the GPU: fimex_amd_project_values / _project_axes /
+_get_vector_reproject_matrix against (a) the fixtures of the reference that cross the PROJ.4 boundary -- the EMEP chain
+cell of test/testInterpolation.cc:280-393 with test/inData.txt, test/outData.txt, the stored lon/lat of test/coordTest.nc,
+the rotation KATs :396-654 -- and (b) the numpy restatement of the same closed forms (oracle/proj_oracle.py).  Device libm
+differs from the host's in the last bits: positions are compared with tolerances, data computed from them bit-exactly in
+the other test files."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from oracle import proj_oracle as po
+from test_oracle_kats import EMEP, LATLONG, _emep_case, _rotation_matrix
+
+pytestmark = pytest.mark.gpu
+
+GEO = "+proj=latlong +R=6371000"
+STERE = "+proj=stere +lat_0=90 +lon_0=0 +lat_ts=60 +a=6371000 +e=0"
+STERE_OBL = "+proj=stere +lat_0=52 +lon_0=10 +R=6371000 +x_0=1000 +y_0=-2000"
+STERE_EQ = "+proj=stere +lat_0=0 +lon_0=-20 +R=6371000"
+STERE_S = "+proj=stere +lat_0=-90 +lon_0=30 +lat_ts=-71 +R=6371000"
+LCC = "+proj=lcc +lat_0=63 +lon_0=15 +lat_1=63 +lat_2=63 +no_defs +R=6.371e+06"
+LCC2 = "+proj=lcc +lat_0=48 +lon_0=8 +lat_1=30 +lat_2=60 +R=6371229"
+MERC = "+proj=merc +lon_0=5 +lat_ts=30 +R=6371000"
+ROT = "+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06 +no_defs"
+ALL = [GEO, STERE, STERE_OBL, STERE_EQ, STERE_S, LCC, LCC2, MERC, ROT]
+
+
+@pytest.fixture(scope="module")
+def fa():
+    from fimex_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1
+    return capi
+
+
+def _is_degree(proj):
+    return po.parse(proj)["proj"] in ("latlong", "longlat", "latlon", "lonlat", "ob_tran")
+
+
+def _close(a, b, proj):
+    scale = 1.0 if _is_degree(proj) else 6.4e6  # radians or metres
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-13 * scale * 10)
+
+
+@pytest.mark.parametrize("dst", ALL)
+def test_project_values_from_geographic_and_back(fa, dst):
+    rng = np.random.default_rng(len(dst))
+    lon = np.radians(rng.uniform(-60, 80, 20000))
+    lat = np.radians(rng.uniform(-75 if dst in (STERE_S, MERC, STERE_EQ) else 20, 85 if dst != STERE_S else -30, 20000))
+    x, y = fa.project_values_host(GEO, dst, lon, lat)
+    wx, wy = po.transform(GEO, dst, lon, lat)
+    _close(x, wx, dst); _close(y, wy, dst)
+    bx, by = fa.project_values_host(dst, GEO, x, y)  # round trip through the inverse
+    np.testing.assert_allclose(bx, lon, atol=1e-11); np.testing.assert_allclose(by, lat, atol=1e-11)
+    assert fa.projection_is_degree(dst) == _is_degree(dst)
+
+
+@pytest.mark.parametrize("src,dst", [(ROT, STERE), (LCC, ROT), (STERE_OBL, MERC), (LCC2, STERE_S)])
+def test_project_axes_between_projections(fa, src, dst):
+    if _is_degree(src):
+        ax, ay = np.radians(np.linspace(-12, 12, 301)), np.radians(np.linspace(15, 45, 200))
+    else:
+        ax, ay = np.linspace(-9e5, 9e5, 301), np.linspace(-7e5, 8e5, 200)
+    gx, gy = fa.project_axes_host(src, dst, ax, ay)
+    wx, wy = po.project_axes(src, dst, ax, ay)
+    assert gx.shape == (200, 301)
+    _close(gx.ravel(), wx, dst); _close(gy.ravel(), wy, dst)
+
+
+def test_unsupported_projection_strings_fail_loudly(fa):
+    for bad in ("+proj=utm +zone=33 +ellps=WGS84", "+proj=stere +lat_0=90 +ellps=WGS84", "+lat_0=3", "+proj=ob_tran +o_proj=stere +R=1"):
+        with pytest.raises(fa.FimexAmdError):
+            fa.project_values_host(GEO, bad, np.zeros(3), np.zeros(3))
+
+
+@pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
+def test_emep_chain_on_the_gpu(fa, golden_dir, method):
+    """test/testInterpolation.cc:280-393 with plan building and regridding on the device: cell (-25, 43) == 32."""
+    import torch
+    field, wpx, wpy, (iS, jS, lonS, latS), lon, lat = _emep_case(golden_dir)
+    n = lonS * latS
+    d = torch.empty(2 * n, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    fa.project_axes_device(LATLONG, EMEP, np.radians(lon), np.radians(lat), d.data_ptr(), d.data_ptr() + 8 * n, st)
+    fa.points2position_device(d.data_ptr(), n, np.arange(iS) + 1., fa.PROJ_AXIS, st)
+    fa.points2position_device(d.data_ptr() + 8 * n, n, np.arange(jS) + 1., fa.PROJ_AXIS, st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d[:n].cpu().numpy(), wpx, atol=1e-9)
+    np.testing.assert_allclose(d[n:].cpu().numpy(), wpy, atol=1e-9)
+    plan = fa.RegridPlan.from_device(method, d.data_ptr(), d.data_ptr() + 8 * n, n, iS, jS, lonS, latS, st)
+    out = plan.apply_host(field[None])[0]
+    assert lon[9] == -25 and lat[25] == 43 and abs(out[25, 9] - 32) < 1e-6
+
+
+def test_emep_outdata_fixture_on_the_gpu(fa, golden_dir):
+    """test/outData.txt (bilinear, axes numbered from 0) through device-built positions."""
+    field, _, _, (iS, jS, lonS, latS), lon, lat = _emep_case(golden_dir)
+    gx, gy = fa.project_axes_host(LATLONG, EMEP, np.radians(lon), np.radians(lat))
+    px = fa.points2position_host(gx.ravel(), np.arange(iS) + 0.)
+    py = fa.points2position_host(gy.ravel(), np.arange(jS) + 0.)
+    out = fa.RegridPlan(oracle.BILINEAR, px, py, iS, jS, lonS, latS).apply_host(field[None])[0].astype(np.float64)
+    want = np.loadtxt(os.path.join(golden_dir, "outData.txt"))[:, 2].reshape(lonS, latS).T
+    both = ~np.isnan(out) & ~np.isnan(want)
+    assert both.sum() > 14000
+    assert (np.abs(out[both] - want[both]) / np.abs(want[both])).max() < 1e-5
+
+
+def test_stere_inverse_against_coordtest_on_the_gpu(fa, golden_dir):
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "coordTest.nc"), "r", mmap=False) as f:
+        x, y = f.variables["x"].data.astype(np.float64), f.variables["y"].data.astype(np.float64)
+        lon, lat = f.variables["longitude"].data.astype(np.float64), f.variables["latitude"].data.astype(np.float64)
+        projstr = f.variables["projection_1"].proj4.decode()
+    lo, la = fa.project_axes_host(projstr, "+proj=latlong +R=6.371e6", x, y)
+    np.testing.assert_allclose(np.degrees(lo), lon, atol=2e-5)
+    np.testing.assert_allclose(np.degrees(la), lat, atol=2e-5)
+
+
+@pytest.mark.parametrize("pin,pout,xa,ya,types", [
+    (STERE, GEO, np.linspace(-25, 25, 60), np.linspace(52, 78, 40), (1, 2)),
+    (GEO, LCC, (np.arange(40) - 19.5) * 25000.0, (np.arange(30) - 14.5) * 25000.0, (0, 0)),
+    (ROT, STERE_OBL, np.linspace(-8e5, 8e5, 33), np.linspace(-6e5, 6e5, 21), (0, 0)),
+    ("+ellps=sphere +a=127.4 +e=0 +proj=stere +lat_0=90 +lon_0=0 +lat_ts=60", "+ellps=sphere +a=127.4 +e=0 +proj=stere +lat_0=90 +lon_0=90 +lat_ts=60",
+     np.arange(5) - 2., np.arange(5) - 2., (0, 0)),
+])
+def test_vector_reproject_matrix_on_the_gpu(fa, pin, pout, xa, ya, types):
+    """mifi_get_vector_reproject_matrix against the restatement that passes the reference's rotation KATs
+    (tests/test_oracle_kats.py: 90 / 180 degree turns, length preservation, direction angles)."""
+    got = fa.get_vector_reproject_matrix_host(pin, pout, xa, ya, types[0], types[1]).reshape(-1, 4)
+    want = _rotation_matrix(pin, pout, xa, ya, types[0], types[1]).reshape(-1, 4)
+    np.testing.assert_allclose(got[:, :3], want[:, :3], atol=2e-6)  # the angle is a difference quotient over 0.1 % of a cell
+    np.testing.assert_allclose(np.hypot(got[:, 0], got[:, 1]), 1.0, atol=1e-14)
+    np.testing.assert_array_equal(got[:, 2], -got[:, 1])
+    np.testing.assert_allclose(np.cos(got[:, 3]), got[:, 0], atol=1e-15)
+
+
+def test_quarter_turn_rotates_u_into_v(fa):
+    """test/testInterpolation.cc:396-453 with the matrix built on the device: lon_0 turned by 90 degrees maps u -> -v, v -> u."""
+    p1 = "+ellps=sphere +a=127.4 +e=0 +proj=stere +lat_0=90 +lon_0=0 +lat_ts=60"
+    p2 = "+ellps=sphere +a=127.4 +e=0 +proj=stere +lat_0=90 +lon_0=90 +lat_ts=60"
+    ax = np.arange(5) - 2.
+    m = fa.get_vector_reproject_matrix_host(p1, p2, ax, ax)
+    u = np.arange(25, dtype=np.float32)
+    v = (25 - np.arange(25)).astype(np.float32)
+    gu, gv = fa.VectorPlan(m, 5, 5).reproject_values_host(u, v)
+    wu, wv = oracle.vector_reproject_values(_rotation_matrix(p1, p2, ax, ax, 0, 0), u, v, 5, 5)
+    np.testing.assert_allclose(np.ravel(gu), np.ravel(wu), atol=1e-4); np.testing.assert_allclose(np.ravel(gv), np.ravel(wv), atol=1e-4)
+    np.testing.assert_allclose(np.hypot(np.ravel(gu), np.ravel(gv)), np.hypot(u, v), rtol=1e-5)
+    np.testing.assert_allclose(np.ravel(gu), v, atol=1e-4)  # u' = v, v' = -u for this turn (testInterpolation.cc:441-447)

@@ -84,6 +84,9 @@ SYMBOLS = {
     "fimex_amd_regrid_slice_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, _Z, ctypes.c_double, ctypes.POINTER(Process2d), _Z,
                                                          _V, ctypes.c_int, ctypes.c_double, _V, ctypes.c_int,
                                                          ctypes.POINTER(Process2d), _Z, _V, _Z, _ZP]),
+    "fimex_amd_get_values_1d_f_device": (ctypes.c_int, [ctypes.c_int, _V, _V, _V, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double, _V]),
+    "fimex_amd_get_values_1d_f_host": (ctypes.c_int, [ctypes.c_int, _F, _F, _F, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
+    "fimex_amd_get_values_linear_d_device": (ctypes.c_int, [_V, _V, _V, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double, _V]),
     "fimex_amd_project_values_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z]),
     "fimex_amd_project_values_device": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _V, _V, _Z, _V]),
     "fimex_amd_project_axes_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z, _Z, _D, _D]),
@@ -352,6 +355,25 @@ def bad2nan_device(d_data, n, bad, stream=0):
 
 def nan2bad_device(d_data, n, bad, stream=0):
     _check(load().fimex_amd_nan2bad_device(d_data, n, bad, stream))
+
+
+BLEND_NEAREST, BLEND_LINEAR, BLEND_LINEAR_WEAK_EXTRAPOL, BLEND_LINEAR_NO_EXTRAPOL, BLEND_LINEAR_CONST_EXTRAPOL, BLEND_LOG, BLEND_LOG_LOG = range(7)
+
+
+def get_values_1d_host(kind, fieldA, fieldB, a, b, x):
+    """mifi_get_values_*_f between two fields; raises where the reference returns MIFI_ERROR."""
+    A, B = _f32(fieldA), _f32(fieldB)
+    out = np.empty(A.shape, np.float32)
+    _check(load().fimex_amd_get_values_1d_f_host(kind, _fp(A.reshape(-1)), _fp(B.reshape(-1)), _fp(out.reshape(-1)), A.size, a, b, x))
+    return out
+
+
+def get_values_1d_device(kind, d_A, d_B, d_out, n, a, b, x, stream=0):
+    _check(load().fimex_amd_get_values_1d_f_device(kind, d_A, d_B, d_out, n, a, b, x, stream))
+
+
+def get_values_linear_d_device(d_A, d_B, d_out, n, a, b, x, stream=0):
+    _check(load().fimex_amd_get_values_linear_d_device(d_A, d_B, d_out, n, a, b, x, stream))
 
 
 def project_values_host(proj_input, proj_output, x, y):

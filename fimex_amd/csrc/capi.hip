@@ -593,6 +593,43 @@ int fimex_amd_points2position_host(double* points, size_t n, const double* axis,
     });
 }
 
+int fimex_amd_get_values_1d_f_device(int kind, const float* d_A, const float* d_B, float* d_out, size_t n, double a, double b, double x, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(n == 0 || (d_A != nullptr && d_B != nullptr && d_out != nullptr), "NULL device buffer");
+        (void)current_device_checked();
+        if (!launch_get_values_1d_f(kind, d_A, d_B, d_out, n, a, b, x, as_stream(stream)))
+            throw Error("log blend needs positive coordinates (src/interpolation.c:1137, 1149)");
+    });
+}
+
+int fimex_amd_get_values_1d_f_host(int kind, const float* A, const float* B, float* out, size_t n, double a, double b, double x)
+{
+    return c_guard([&] {
+        FA_REQUIRE(n == 0 || (A != nullptr && B != nullptr && out != nullptr), "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<float> d(3 * n);
+        if (n) {
+            FA_HIP(hipMemcpyAsync(d.get(), A, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
+            FA_HIP(hipMemcpyAsync(d.get() + n, B, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
+        }
+        if (!launch_get_values_1d_f(kind, d.get(), d.get() + n, d.get() + 2 * n, n, a, b, x, stream.get()))
+            throw Error("log blend needs positive coordinates (src/interpolation.c:1137, 1149)");
+        if (n) FA_HIP(hipMemcpyAsync(out, d.get() + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_get_values_linear_d_device(const double* d_A, const double* d_B, double* d_out, size_t n, double a, double b, double x, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(n == 0 || (d_A != nullptr && d_B != nullptr && d_out != nullptr), "NULL device buffer");
+        (void)current_device_checked();
+        launch_get_values_linear_d(d_A, d_B, d_out, n, a, b, x, as_stream(stream));
+    });
+}
+
 int fimex_amd_project_values_device(const char* proj_input, const char* proj_output, double* d_x, double* d_y, size_t num, void* stream)
 {
     return c_guard([&] {

@@ -4,6 +4,7 @@
 // mifi_points2position (src/interpolation.c:104-217).
 #include "plan.hpp"
 
+#include <cmath>
 #include <string>
 #include <type_traits>
 
@@ -229,6 +230,103 @@ __global__ void __launch_bounds__(kBlock) points2position_kernel(P2PArgs a)
 
 void launch_bad2nan(float* d, size_t n, float bad, hipStream_t stream) { launch_replace<true>(d, n, bad, stream); }
 void launch_nan2bad(float* d, size_t n, float bad, hipStream_t stream) { launch_replace<false>(d, n, bad, stream); }
+
+// ---- 1-D blends between two fields (time / vertical interpolation), src/interpolation.c:1030-1156
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) blend_kernel(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ out, size_t n, T f)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const T iA = A[i], iB = B[i];
+        out[i] = iA + f * (iB - iA);  // :1046 / :1078
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) undefined_kernel(float* __restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = undefined_f();
+}
+
+template <typename T>
+void copy_field(const T* src, T* dst, size_t n, hipStream_t stream)  // the reference's memcpy: no 0 * NaN side effects
+{
+    if (src != dst) FA_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+}
+
+template <typename T>
+void blend(const T* A, const T* B, T* out, size_t n, T f, hipStream_t stream)
+{
+    blend_kernel<T><<<stream_blocks(n), kBlock, 0, stream>>>(A, B, out, n, f);
+    FA_HIP(hipGetLastError());
+}
+
+// mifi_get_values_linear_f, :1050-1063
+void linear_f(const float* A, const float* B, float* out, size_t n, double a, double b, double x, hipStream_t stream)
+{
+    const float f = (a == b) ? 0 : ((x - a) / (b - a));
+    if (f == 0) copy_field(A, out, n, stream);
+    else if (f == 1) copy_field(B, out, n, stream);
+    else blend(A, B, out, n, f, stream);
+}
+
+// mifi_get_values_linear_conf_extrapol_f, :1085-1104
+void linear_conf_extrapol_f(float left, float right, const float* A, const float* B, float* out, size_t n, double a, double b, double x,
+                            hipStream_t stream)
+{
+    const float f = (a == b) ? 0 : ((x - a) / (b - a));
+    if (f == 0) copy_field(A, out, n, stream);
+    else if (f == 1) copy_field(B, out, n, stream);
+    else if ((f >= left) && (f <= right)) blend(A, B, out, n, f, stream);
+    else {
+        undefined_kernel<<<stream_blocks(n), kBlock, 0, stream>>>(out, n);
+        FA_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace
+
+// returns false where the reference returns MIFI_ERROR (non-positive coordinates of the log blends)
+bool launch_get_values_1d_f(int kind, const float* A, const float* B, float* out, size_t n, double a, double b, double x, hipStream_t stream)
+{
+    switch (kind) {
+    case FIMEX_AMD_1D_NEAREST: if (n) copy_field(A, out, n, stream); return true;  // :1030-1034
+    case FIMEX_AMD_1D_LINEAR: if (n) linear_f(A, B, out, n, a, b, x, stream); return true;
+    case FIMEX_AMD_1D_LINEAR_WEAK_EXTRAPOL: if (n) linear_conf_extrapol_f(-1.f, 2.f, A, B, out, n, a, b, x, stream); return true;  // :1106-1109
+    case FIMEX_AMD_1D_LINEAR_NO_EXTRAPOL: if (n) linear_conf_extrapol_f(0.f, 1.f, A, B, out, n, a, b, x, stream); return true;     // :1110-1113
+    case FIMEX_AMD_1D_LINEAR_CONST_EXTRAPOL: {  // :1115-1126
+        const float f = (a == b) ? 0 : ((x - a) / (b - a));
+        if (n == 0) return true;
+        if (f >= 1) copy_field(B, out, n, stream);
+        else if (f <= 0) copy_field(A, out, n, stream);
+        else blend(A, B, out, n, f, stream);
+        return true;
+    }
+    case FIMEX_AMD_1D_LOG:  // :1134-1145; the three logarithms are taken on the host, by the same libm as the reference's
+        if (a <= 0 || b <= 0 || x <= 0) return false;
+        if (n) linear_f(A, B, out, n, std::log(a), std::log(b), std::log(x), stream);
+        return true;
+    case FIMEX_AMD_1D_LOG_LOG: {  // :1147-1156
+        if (a <= 0 || b <= 0 || x <= 0) return false;
+        const double la = std::log(a + M_E), lb = std::log(b + M_E), lx = std::log(x + M_E);
+        if (!(la <= 0 || lb <= 0 || lx <= 0) && n) linear_f(A, B, out, n, std::log(la), std::log(lb), std::log(lx), stream);
+        return true;  // the reference drops the inner status
+    }
+    default: throw Error("unknown 1-D blend " + std::to_string(kind));
+    }
+}
+
+// mifi_get_values_linear_d, :1065-1083
+void launch_get_values_linear_d(const double* A, const double* B, double* out, size_t n, double a, double b, double x, hipStream_t stream)
+{
+    if (n == 0) return;
+    const double f = (a == b) ? 0 : ((x - a) / (b - a));
+    if (f == 0) copy_field(A, out, n, stream);
+    else if (f == 1) copy_field(B, out, n, stream);
+    else blend(A, B, out, n, f, stream);
+}
 
 size_t cdm_type_size(int cdmType)
 {

@@ -95,6 +95,8 @@ void launch_vector_direction(const fimex_amd_vector_plan& plan, float* d_angles,
 void launch_bad2nan(float* d, size_t n, float bad, hipStream_t stream);
 void launch_nan2bad(float* d, size_t n, float bad, hipStream_t stream);
 void launch_points2position(double* d_points, size_t n, const double* h_axis, int num, int axisType, hipStream_t stream);
+bool launch_get_values_1d_f(int kind, const float* A, const float* B, float* out, size_t n, double a, double b, double x, hipStream_t stream);
+void launch_get_values_linear_d(const double* A, const double* B, double* out, size_t n, double a, double b, double x, hipStream_t stream);
 size_t cdm_type_size(int cdmType);  // throws for types without a float form
 void launch_data2interpolation(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, hipStream_t stream);
 void launch_interpolation2data(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, hipStream_t stream);

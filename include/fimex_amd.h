@@ -253,6 +253,23 @@ int fimex_amd_points2position_device(double* d_points, size_t n, const double* a
 /** Same on n host doubles (copied to the GPU and back). */
 int fimex_amd_points2position_host(double* points, size_t n, const double* axis, int num, int axis_type);
 
+/* ------------------------------------------ 1-D blends between two fields (8f n4) */
+/** mifi_get_values_{nearest, linear, linear_weak_extrapol, linear_no_extrapol, linear_const_extrapol, log, log_log}_f
+ *  (include/fimex/interpolation.h, src/interpolation.c:1030-1156): outfield = blend of infieldA (at coordinate a) and
+ *  infieldB (at b) at coordinate x, n values, as the time and vertical interpolators call them.  out may alias A or B.
+ *  Returns FIMEX_AMD_ERROR where the reference returns MIFI_ERROR (non-positive a, b or x for the log blends). */
+typedef enum fimex_amd_blend1d {
+    FIMEX_AMD_1D_NEAREST = 0, FIMEX_AMD_1D_LINEAR, FIMEX_AMD_1D_LINEAR_WEAK_EXTRAPOL, FIMEX_AMD_1D_LINEAR_NO_EXTRAPOL,
+    FIMEX_AMD_1D_LINEAR_CONST_EXTRAPOL, FIMEX_AMD_1D_LOG, FIMEX_AMD_1D_LOG_LOG
+} fimex_amd_blend1d;
+int fimex_amd_get_values_1d_f_device(int kind, const float* d_infieldA, const float* d_infieldB, float* d_outfield, size_t n,
+                                     double a, double b, double x, void* stream);
+int fimex_amd_get_values_1d_f_host(int kind, const float* infieldA, const float* infieldB, float* outfield, size_t n,
+                                   double a, double b, double x);
+/** mifi_get_values_linear_d, src/interpolation.c:1065-1083. */
+int fimex_amd_get_values_linear_d_device(const double* d_infieldA, const double* d_infieldB, double* d_outfield, size_t n,
+                                         double a, double b, double x, void* stream);
+
 /* ----------------------------------- plan building across projections (8f n2) */
 /* The reference calls PROJ.4 (pj_init_plus / pj_transform) here; this library carries its own spherical projections:
  * latlong/longlat, stere, lcc, merc, ob_tran with o_proj=longlat (radians at this boundary for geographic and rotated

@@ -77,6 +77,10 @@ def _declare(L):
     L.orc_bad2nanf.restype = _Z
     L.orc_nanf2bad.argtypes = [_F, _F, ctypes.c_float]
     L.orc_nanf2bad.restype = _Z
+    L.orc_get_values_1d_f.argtypes = [ctypes.c_int, _F, _F, _F, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    L.orc_get_values_1d_f.restype = ctypes.c_int
+    L.orc_get_values_linear_d.argtypes = [_D, _D, _D, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    L.orc_get_values_linear_d.restype = ctypes.c_int
     L.orc_data2interpolation_array.argtypes = [ctypes.c_void_p, ctypes.c_int, _Z, ctypes.c_double, _F]
     L.orc_data2interpolation_array.restype = ctypes.c_int
     L.orc_interpolation_array2data.argtypes = [_F, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
@@ -247,6 +251,24 @@ def interpolation_array2data(a, newType, bad):
     rc = lib().orc_interpolation_array2data(_f(a.reshape(-1)), ctypes.c_size_t(a.size), newType, ctypes.c_double(bad),
                                             ctypes.c_void_p(out.ctypes.data))
     assert rc == OK
+    return out
+
+
+BLEND_NEAREST, BLEND_LINEAR, BLEND_LINEAR_WEAK_EXTRAPOL, BLEND_LINEAR_NO_EXTRAPOL, BLEND_LINEAR_CONST_EXTRAPOL, BLEND_LOG, BLEND_LOG_LOG = range(7)
+
+
+def get_values_1d(kind, fieldA, fieldB, a, b, x):
+    """mifi_get_values_{nearest,linear*,log,log_log}_f: (out, return code)."""
+    A, B = _c32(fieldA), _c32(fieldB)
+    out = np.full(A.shape, -12345.0, np.float32)
+    rc = lib().orc_get_values_1d_f(kind, _f(A.reshape(-1)), _f(B.reshape(-1)), _f(out.reshape(-1)), A.size, a, b, x)
+    return out, rc
+
+
+def get_values_linear_d(fieldA, fieldB, a, b, x):
+    A, B = np.ascontiguousarray(fieldA, np.float64), np.ascontiguousarray(fieldB, np.float64)
+    out = np.empty(A.shape)
+    assert lib().orc_get_values_linear_d(_d(A.reshape(-1)), _d(B.reshape(-1)), _d(out.reshape(-1)), A.size, a, b, x) == OK
     return out
 
 

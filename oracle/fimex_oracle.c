@@ -716,3 +716,71 @@ int orc_interpolation_array2data(const float* in, size_t n, int newType, double 
 #undef ORC_SCALE_FLT
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------- 1-D blends (n4) */
+/* src/interpolation.c:1038-1049 */
+static void orc_linear_simple(const float* A, const float* B, float* out, size_t n, float f)
+{
+    for (size_t i = 0; i < n; ++i) out[i] = A[i] + f * (B[i] - A[i]);
+}
+
+/* :1050-1063 */
+static int orc_linear_f(const float* A, const float* B, float* out, size_t n, double a, double b, double x)
+{
+    const float f = (a == b) ? 0 : ((x - a) / (b - a));
+    if (f == 0) memcpy(out, A, n * sizeof(float));
+    else if (f == 1) memcpy(out, B, n * sizeof(float));
+    else orc_linear_simple(A, B, out, n, f);
+    return ORC_OK;
+}
+
+/* :1085-1104 */
+static int orc_linear_conf_extrapol_f(float left, float right, const float* A, const float* B, float* out, size_t n, double a, double b, double x)
+{
+    const float f = (a == b) ? 0 : ((x - a) / (b - a));
+    if (f == 0) memcpy(out, A, n * sizeof(float));
+    else if (f == 1) memcpy(out, B, n * sizeof(float));
+    else if ((f >= left) && (f <= right)) orc_linear_simple(A, B, out, n, f);
+    else for (size_t i = 0; i < n; ++i) out[i] = orc_nanf();
+    return ORC_OK;
+}
+
+/* :1134-1145 */
+static int orc_log_f(const float* A, const float* B, float* out, size_t n, double a, double b, double x)
+{
+    if (a <= 0 || b <= 0 || x <= 0) return ORC_ERROR;
+    return orc_linear_f(A, B, out, n, log(a), log(b), log(x));
+}
+
+int orc_get_values_1d_f(int kind, const float* A, const float* B, float* out, size_t n, double a, double b, double x)
+{
+    switch (kind) {
+    case ORC_1D_NEAREST: memcpy(out, A, n * sizeof(float)); return ORC_OK;            /* :1030-1034 */
+    case ORC_1D_LINEAR: return orc_linear_f(A, B, out, n, a, b, x);
+    case ORC_1D_LINEAR_WEAK_EXTRAPOL: return orc_linear_conf_extrapol_f(-1.f, 2.f, A, B, out, n, a, b, x); /* :1106-1109 */
+    case ORC_1D_LINEAR_NO_EXTRAPOL: return orc_linear_conf_extrapol_f(0.f, 1.f, A, B, out, n, a, b, x);    /* :1110-1113 */
+    case ORC_1D_LINEAR_CONST_EXTRAPOL: {                                                /* :1115-1126 */
+        const float f = (a == b) ? 0 : ((x - a) / (b - a));
+        if (f >= 1) memcpy(out, B, n * sizeof(float));
+        else if (f <= 0) memcpy(out, A, n * sizeof(float));
+        else orc_linear_simple(A, B, out, n, f);
+        return ORC_OK;
+    }
+    case ORC_1D_LOG: return orc_log_f(A, B, out, n, a, b, x);
+    case ORC_1D_LOG_LOG:                                                                /* :1147-1156 */
+        if (a <= 0 || b <= 0 || x <= 0) return ORC_ERROR;
+        orc_log_f(A, B, out, n, log(a + M_E), log(b + M_E), log(x + M_E));              /* the inner status is dropped there too */
+        return ORC_OK;
+    default: return ORC_ERROR;
+    }
+}
+
+/* :1065-1083 */
+int orc_get_values_linear_d(const double* A, const double* B, double* out, size_t n, double a, double b, double x)
+{
+    const double f = (a == b) ? 0 : ((x - a) / (b - a));
+    if (f == 0) memcpy(out, A, n * sizeof(double));
+    else if (f == 1) memcpy(out, B, n * sizeof(double));
+    else for (size_t i = 0; i < n; ++i) out[i] = A[i] + f * (B[i] - A[i]);
+    return ORC_OK;
+}

@@ -78,6 +78,12 @@ int orc_points2position(double* points, size_t n, const double* axis, int num, i
 size_t orc_bad2nanf(float* begin, float* end, float badVal);
 size_t orc_nanf2bad(float* begin, float* end, float badVal);
 
+/* 1-D blends between two fields (time / vertical interpolation), src/interpolation.c:1030-1156 */
+enum { ORC_1D_NEAREST = 0, ORC_1D_LINEAR, ORC_1D_LINEAR_WEAK_EXTRAPOL, ORC_1D_LINEAR_NO_EXTRAPOL, ORC_1D_LINEAR_CONST_EXTRAPOL,
+       ORC_1D_LOG, ORC_1D_LOG_LOG };
+int orc_get_values_1d_f(int kind, const float* infieldA, const float* infieldB, float* outfield, size_t n, double a, double b, double x);
+int orc_get_values_linear_d(const double* infieldA, const double* infieldB, double* outfield, size_t n, double a, double b, double x);
+
 /* CDMDataType, include/fimex/CDMDataType.h:35-49 */
 enum {
     ORC_CDM_NAT = 0, ORC_CDM_CHAR, ORC_CDM_SHORT, ORC_CDM_INT, ORC_CDM_FLOAT, ORC_CDM_DOUBLE, ORC_CDM_STRING,

@@ -512,3 +512,49 @@ def test_regrid_slice_typed_matches_the_reference_sequence(fa, dt, bad):
         b = fa.regrid_slice_host(plan, u, bad)
         ok = ~np.isnan(b)
         assert cases.same(np.where(a == 0, 0 * a, a), np.where(b == 0, 0 * b, b))  # apart from -0.0 -> +0.0 (ScaleValue)
+
+
+# ---------------------------------------------------------------- 1-D blends between two fields
+@pytest.mark.parametrize("kind", range(7))
+@pytest.mark.parametrize("abx", [(1., 2., 1.5), (1., 1., .5), (0., 1., 2.), (0., 1., 1.), (0., 1., 0.), (0., 1., -.5), (0., 1., -1.5), (0., 1., 2.5),
+                                 (1000., 100., 500.), (1000., 100., 1500.), (1000., 100., 100.), (3., 7., 3.0000001)])
+def test_blends_between_two_fields_match_oracle(fa, kind, abx):
+    a, b, x = abx
+    A = cases.field(1, 37, 53, seed=kind + 1, nan_frac=0.05)[0]
+    B = cases.field(1, 37, 53, seed=kind + 50, nan_frac=0.05)[0]
+    want, rc = oracle.get_values_1d(kind, A, B, a, b, x)
+    if rc != oracle.OK:
+        with pytest.raises(fa.FimexAmdError):
+            fa.get_values_1d_host(kind, A, B, a, b, x)
+        return
+    got = fa.get_values_1d_host(kind, A, B, a, b, x)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+def test_log_blends_reject_non_positive_coordinates_and_kats(fa):
+    A, B = np.array([1000.], np.float32), np.array([100.], np.float32)
+    for kind in (fa.BLEND_LOG, fa.BLEND_LOG_LOG):
+        for abx in ((0., 1., 2.), (1., -1., 2.), (1., 2., 0.)):
+            with pytest.raises(fa.FimexAmdError):
+                fa.get_values_1d_host(kind, A, B, *abx)
+    # test/testInterpolation.cc:212-262
+    for x, w in ((500., 729.073), (1500., 1158.482), (200., 370.927), (800., 912.781)):
+        assert abs(fa.get_values_1d_host(fa.BLEND_LOG, A, B, 1000., 100., x)[0] - w) / w < 1e-5
+    for x, w in ((500., 763.1873), (200., 408.0904), (800., 926.384)):
+        assert abs(fa.get_values_1d_host(fa.BLEND_LOG_LOG, A, B, 1000., 100., x)[0] - w) / w < 1e-5
+
+
+def test_blend_device_in_place_and_double(fa):
+    import torch
+    rng = np.random.default_rng(2)
+    A, B = rng.normal(0, 5, 100001), rng.normal(3, 5, 100001)
+    tA, tB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    out = torch.empty_like(tA)
+    fa.get_values_linear_d_device(tA.data_ptr(), tB.data_ptr(), out.data_ptr(), A.size, 2., 5., 3.)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.get_values_linear_d(A, B, 2., 5., 3.))
+    fA, fB = torch.from_numpy(A.astype(np.float32)).cuda(), torch.from_numpy(B.astype(np.float32)).cuda()
+    want = oracle.get_values_1d(oracle.BLEND_LINEAR, A.astype(np.float32), B.astype(np.float32), 2., 5., 3.)[0]
+    fa.get_values_1d_device(fa.BLEND_LINEAR, fA.data_ptr(), fB.data_ptr(), fA.data_ptr(), A.size, 2., 5., 3.)  # out aliases A
+    torch.cuda.synchronize()
+    assert cases.same(fA.cpu().numpy(), want)

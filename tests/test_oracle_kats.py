@@ -11,6 +11,7 @@ import pytest
 
 import oracle
 from oracle import proj_oracle as po
+import cases
 
 EMEP = "+ellps=sphere +a=127.4 +e=0 +proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +x_0=7 +y_0=109"
 LATLONG = "+ellps=sphere +a=6370 +e=0 +proj=latlong"
@@ -248,3 +249,42 @@ def test_vector_direction_angles():
 def test_project_axes_near_pole():
     ox, oy = po.project_axes(EMEP, LATLONG, [6, 7, 8], [108, 109, 110])
     assert np.all(np.degrees(oy) > 89)
+
+
+# ---- test/testInterpolation.cc:158-262: 1-D blends between two fields
+def test_linear_blend_kats():
+    A = np.array([0, 1, -1, 1], np.float32)
+    B = np.array([1, -1, 0, 1], np.float32)
+    out, rc = oracle.get_values_1d(oracle.BLEND_LINEAR, A, B, 1., 1., .5)      # a == b: field A
+    assert rc == oracle.OK and np.allclose(out, A, rtol=1e-7)
+    out, rc = oracle.get_values_1d(oracle.BLEND_LINEAR, A, B, 1., 2., 1.5)
+    assert np.allclose(out, np.float32(.5) * (A + B), rtol=1e-7)
+    out, rc = oracle.get_values_1d(oracle.BLEND_LINEAR, A, B, 0., 1., 2.)      # extrapolation
+    assert np.allclose(out, A + 2 * (B - A), rtol=1e-7)
+    d = oracle.get_values_linear_d(A, B, 1., 2., 1.5)
+    assert np.allclose(d, .5 * (A.astype(float) + B), rtol=1e-12)
+    assert np.allclose(oracle.get_values_linear_d(A, B, 0., 1., 2.), A.astype(float) + 2 * (B.astype(float) - A), rtol=1e-12)
+
+
+def test_log_blend_kats():
+    A, B = np.array([1000.], np.float32), np.array([100.], np.float32)
+    for x, want in ((100., 100.), (1000., 1000.), (500., 729.073), (1500., 1158.482), (200., 370.927), (800., 912.781)):
+        out, rc = oracle.get_values_1d(oracle.BLEND_LOG, A, B, 1000., 100., x)
+        assert rc == oracle.OK and abs(out[0] - want) / want < 1e-5, (x, out[0])
+    for x, want in ((500., 763.1873), (200., 408.0904), (800., 926.384)):    # "results from NCLs vintp2p_ecmwf"
+        out, rc = oracle.get_values_1d(oracle.BLEND_LOG_LOG, A, B, 1000., 100., x)
+        assert rc == oracle.OK and abs(out[0] - want) / want < 1e-5, (x, out[0])
+    assert oracle.get_values_1d(oracle.BLEND_LOG, A, B, 1000., 100., -1.)[1] == oracle.ERROR
+    assert oracle.get_values_1d(oracle.BLEND_LOG_LOG, A, B, 0., 100., 5.)[1] == oracle.ERROR
+
+
+def test_extrapolation_variants_of_the_linear_blend():
+    A, B = np.array([1, 2, np.nan], np.float32), np.array([3, 6, 1], np.float32)
+    weak = lambda x: oracle.get_values_1d(oracle.BLEND_LINEAR_WEAK_EXTRAPOL, A, B, 0., 1., x)[0]
+    none = lambda x: oracle.get_values_1d(oracle.BLEND_LINEAR_NO_EXTRAPOL, A, B, 0., 1., x)[0]
+    const = lambda x: oracle.get_values_1d(oracle.BLEND_LINEAR_CONST_EXTRAPOL, A, B, 0., 1., x)[0]
+    assert cases.same(weak(1.5), A + np.float32(1.5) * (B - A)) and np.isnan(weak(2.5)).all() and np.isnan(weak(-1.5)).all()
+    assert cases.same(none(.25), A + np.float32(.25) * (B - A)) and np.isnan(none(1.25)).all()
+    assert cases.same(none(0.), A) and cases.same(none(1.), B)   # copies: no 0 * NaN side effects
+    assert cases.same(const(7.), B) and cases.same(const(-3.), A) and cases.same(const(.5), A + np.float32(.5) * (B - A))
+    assert cases.same(oracle.get_values_1d(oracle.BLEND_NEAREST, A, B, 0., 1., .9)[0], A)

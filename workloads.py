@@ -46,6 +46,9 @@ class BilinearRotatedPole:
     (SURVEY 8d asks for >=95 % / ~1 %; a rectangle in rotated coordinates cannot meet both, coverage won).
     """
 
+    source_proj = "+proj=latlong +R=6.371e6"
+    target_proj = "+proj=ob_tran +o_proj=longlat +lon_0=0 +o_lat_p=60 +R=6.371e6"
+
     def __init__(self, scale=1):
         # scale > 1 shrinks every axis by that factor (same geometry, fewer cells) for tests
         self.inX, self.inY = 4000 // scale, 3000 // scale
@@ -63,6 +66,9 @@ class BilinearRotatedPole:
 
     def source_axes_rad(self):
         return np.radians(self.src_lon), np.radians(self.src_lat)
+
+    def target_axes_deg(self):
+        return self.rlon, self.rlat
 
     def base_field(self):
         """f = 280 + 20 sin(3 lon) cos(5 lat) + N(0,1), 0.1 % NaN (float32 [inY][inX])."""

@@ -204,7 +204,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "kernel": "bilinear_apply_staged" if args.method == "bilinear" else args.method + "_apply",
+            "kernel": ("staged_apply<%d, ...>" % (2 if args.method == "bilinear" else 4)) if info.get("stagedCells") else args.method + "_apply",
+            "staged_cells_per_slice": info.get("stagedCells"), "tile": [info.get("tileW"), info.get("tileH")],
             "kernel_ms_avg": avg_kernel_ms, "kernel_ms_min": float(np.min(kernel_ms)),
             "algorithmic_bytes_per_launch": alg_bytes,
             "n_src_bbox": n_src_bbox, "n_src_touched": n_src_touched, "plan_bytes": info["planBytes"],

@@ -93,6 +93,12 @@ SYMBOLS = {
     "fimex_amd_project_axes_device": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z, _Z, _V, _V, _V]),
     "fimex_amd_get_vector_reproject_matrix_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, ctypes.c_int, ctypes.c_int, _Z, _Z, _D]),
     "fimex_amd_get_vector_reproject_matrix_device": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, ctypes.c_int, ctypes.c_int, _Z, _Z, _V, _V]),
+    "fimex_amd_get_vector_reproject_matrix_field_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, _D, _D, _Z, _Z, _D]),
+    "fimex_amd_get_vector_reproject_matrix_points_host": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, _D, _D, _Z, _D]),
+    "fimex_amd_vector_reproject_direction_scaled_host": (ctypes.c_int, [_V, _F, _Z, ctypes.c_double, ctypes.c_double]),
+    "fimex_amd_vector_reproject_direction_scaled_device": (ctypes.c_int, [_V, _V, _Z, ctypes.c_double, ctypes.c_double, _V]),
+    "fimex_amd_rotate_vector_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_double, _V, ctypes.c_int, ctypes.c_double, _Z, ctypes.c_int,
+                                                          ctypes.c_int, ctypes.c_double, _V]),
     "fimex_amd_projection_is_degree": (ctypes.c_int, [ctypes.c_char_p]),
     "fimex_amd_scan_sum_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _ZP, _V]),
 }
@@ -238,6 +244,12 @@ class VectorPlan:
 
     def reproject_direction_device(self, d_angles, oz, stream=0):
         _check(load().fimex_amd_vector_reproject_direction_device(self._h, d_angles, oz, stream))
+
+    def reproject_direction_scaled_host(self, angles, scale, offset):
+        """packed angles: scale * a + offset, rotate, (a - offset) / scale (src/CDMProcessor.cc:621-636)."""
+        a = _f32(angles).copy()
+        _check(load().fimex_amd_vector_reproject_direction_scaled_host(self._h, _fp(a.reshape(-1)), a.size, scale, offset))
+        return a
 
 
 def fill2d_process(relaxCrit, corrEff, maxLoop):
@@ -410,6 +422,32 @@ def get_vector_reproject_matrix_device(proj_input, proj_output, outXAxis, outYAx
     ax, ay = _f64(outXAxis).ravel(), _f64(outYAxis).ravel()
     _check(load().fimex_amd_get_vector_reproject_matrix_device(proj_input.encode(), proj_output.encode(), _dp(ax), _dp(ay), xAxisType, yAxisType,
                                                                ax.size, ay.size, d_matrix, stream))
+
+
+def get_vector_reproject_matrix_field_host(proj_input, proj_output, inXField, inYField):
+    fx, fy = _f64(inXField), _f64(inYField)
+    oy, ox = fx.shape
+    m = np.empty(4 * fx.size)
+    _check(load().fimex_amd_get_vector_reproject_matrix_field_host(proj_input.encode(), proj_output.encode(), _dp(fx.reshape(-1)), _dp(fy.reshape(-1)), ox, oy, _dp(m)))
+    return m
+
+
+def get_vector_reproject_matrix_points_host(proj_input, proj_output, inputIsMetric, outX, outY):
+    px, py = _f64(outX).ravel(), _f64(outY).ravel()
+    m = np.empty(4 * px.size)
+    _check(load().fimex_amd_get_vector_reproject_matrix_points_host(proj_input.encode(), proj_output.encode(), 1 if inputIsMetric else 0, _dp(px), _dp(py), px.size, _dp(m)))
+    return m
+
+
+def rotate_vector_typed_host(vec, xData, xFill, yData, yFill, returnX=True, outFill=None):
+    """CDMProcessor's vector rotation on stored types; returns the requested component in its own type."""
+    x, y = np.ascontiguousarray(xData), np.ascontiguousarray(yData)
+    keep = x if returnX else y
+    out = np.empty(keep.shape, keep.dtype)
+    _check(load().fimex_amd_rotate_vector_typed_host(vec._h, x.ctypes.data, cdm_type_of(x.dtype), xFill, y.ctypes.data, cdm_type_of(y.dtype), yFill,
+                                                     x.size, 1 if returnX else 0, cdm_type_of(keep.dtype),
+                                                     (xFill if returnX else yFill) if outFill is None else outFill, out.ctypes.data))
+    return out
 
 
 def projection_is_degree(proj):

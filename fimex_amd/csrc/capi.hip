@@ -713,6 +713,87 @@ int fimex_amd_get_vector_reproject_matrix_host(const char* proj_input, const cha
     });
 }
 
+int fimex_amd_get_vector_reproject_matrix_field_host(const char* proj_input, const char* proj_output, const double* in_x_field,
+                                                     const double* in_y_field, size_t ox, size_t oy, double* matrix)
+{
+    return c_guard([&] {
+        const size_t n = ox * oy;
+        FA_REQUIRE(n == 0 || (in_x_field != nullptr && in_y_field != nullptr && matrix != nullptr), "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(4 * n);
+        launch_vector_reproject_matrix_field(proj_input, proj_output, in_x_field, in_y_field, ox, oy, d.get(), stream.get());
+        if (n) FA_HIP(hipMemcpyAsync(matrix, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_get_vector_reproject_matrix_points_host(const char* proj_input, const char* proj_output, int inputIsMetric,
+                                                      const double* out_x_points, const double* out_y_points, size_t on, double* matrix)
+{
+    return c_guard([&] {
+        FA_REQUIRE(on == 0 || (out_x_points != nullptr && out_y_points != nullptr && matrix != nullptr), "NULL argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(4 * on);
+        launch_vector_reproject_matrix_points(proj_input, proj_output, inputIsMetric, out_x_points, out_y_points, on, d.get(), stream.get());
+        if (on) FA_HIP(hipMemcpyAsync(matrix, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_vector_reproject_direction_scaled_device(const fimex_amd_vector_plan* plan, float* d_angles, size_t oz, double scale,
+                                                       double offset, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr && (oz == 0 || d_angles != nullptr), "NULL argument");
+        ScopedDevice dev(plan->device);
+        launch_vector_direction_scaled(*plan, d_angles, oz, scale, offset, as_stream(stream));
+    });
+}
+
+int fimex_amd_vector_reproject_direction_scaled_host(const fimex_amd_vector_plan* plan, float* angles, size_t size, double scale, double offset)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL argument");
+        const size_t layer = plan->ox * plan->oy, oz = layer ? size / layer : 0;
+        if (oz == 0) return;
+        FA_REQUIRE(angles != nullptr, "NULL argument");
+        ScopedDevice dev(plan->device);
+        ScopedStream stream;
+        DeviceArray<float> d(oz * layer);
+        FA_HIP(hipMemcpyAsync(d.get(), angles, d.bytes(), hipMemcpyHostToDevice, stream.get()));
+        launch_vector_direction_scaled(*plan, d.get(), oz, scale, offset, stream.get());
+        FA_HIP(hipMemcpyAsync(angles, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        stream.sync();
+    });
+}
+
+int fimex_amd_rotate_vector_typed_host(const fimex_amd_vector_plan* plan, const void* xData, int xType, double xFill, const void* yData,
+                                       int yType, double yFill, size_t size, int returnX, int outType, double outFill, void* outData)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL argument");
+        const size_t ex = cdm_type_size(xType), ey = cdm_type_size(yType), eo = cdm_type_size(outType);
+        const size_t layer = plan->ox * plan->oy, oz = layer ? size / layer : 0;
+        if (size == 0) return;
+        FA_REQUIRE(xData != nullptr && yData != nullptr && outData != nullptr, "NULL argument");
+        ScopedDevice dev(plan->device);
+        ScopedStream stream;
+        hipStream_t st = stream.get();
+        DeviceArray<unsigned char> rawX(size * ex), rawY(size * ey), rawOut(size * eo);
+        DeviceArray<float> u(size), v(size);
+        FA_HIP(hipMemcpyAsync(rawX.get(), xData, rawX.bytes(), hipMemcpyHostToDevice, st));
+        FA_HIP(hipMemcpyAsync(rawY.get(), yData, rawY.bytes(), hipMemcpyHostToDevice, st));
+        launch_data2interpolation(rawX.get(), xType, size, xFill, u.get(), st);   // CDMProcessor.cc:607-608
+        launch_data2interpolation(rawY.get(), yType, size, yFill, v.get(), st);
+        launch_vector_values(*plan, u.get(), v.get(), oz, st);                      // :612 (whole slices only, as the reference)
+        launch_interpolation2data(returnX ? u.get() : v.get(), size, outType, outFill, rawOut.get(), st);  // :614-618
+        FA_HIP(hipMemcpyAsync(outData, rawOut.get(), rawOut.bytes(), hipMemcpyDeviceToHost, st));
+        stream.sync();
+    });
+}
+
 int fimex_amd_projection_is_degree(const char* proj)
 {
     int r = -1;

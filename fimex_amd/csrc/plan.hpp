@@ -89,6 +89,7 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
 // vector.hip
 void build_vector_plan(fimex_amd_vector_plan& plan, const double* h_matrix);
 void launch_vector_values(const fimex_amd_vector_plan& plan, float* d_u, float* d_v, size_t oz, hipStream_t stream);
+void launch_vector_direction_scaled(const fimex_amd_vector_plan& plan, float* d_angles, size_t oz, double scale, double offset, hipStream_t stream);
 void launch_vector_direction(const fimex_amd_vector_plan& plan, float* d_angles, size_t oz, hipStream_t stream);
 
 // convert.hip
@@ -107,6 +108,10 @@ void launch_project_axes(const char* projIn, const char* projOut, const double* 
                          double* d_outX, double* d_outY, hipStream_t stream);
 void launch_vector_reproject_matrix(const char* projIn, const char* projOut, const double* h_outXAxis, const double* h_outYAxis,
                                     int xAxisType, int yAxisType, size_t ox, size_t oy, double* d_matrix, hipStream_t stream);
+void launch_vector_reproject_matrix_field(const char* projIn, const char* projOut, const double* h_inX, const double* h_inY, size_t ox,
+                                          size_t oy, double* d_matrix, hipStream_t stream);
+void launch_vector_reproject_matrix_points(const char* projIn, const char* projOut, int inputIsMetric, const double* h_outX,
+                                           const double* h_outY, size_t on, double* d_matrix, hipStream_t stream);
 int projection_is_degree(const char* proj);
 
 // fill.hip

@@ -281,15 +281,16 @@ __device__ __forceinline__ double bearing(double lat0, double lon0, double lat1,
 
 // mifi_get_vector_reproject_matrix_points_proj_delta (interpolation.c:330-438): per point of the output mesh the angle of
 // the input projection's x direction (and y direction) seen in the output projection, from two finite differences
+// outX / outY: the two axes of the output mesh (axes != 0) or one value per point
 __global__ void __launch_bounds__(kBlock) vector_matrix_kernel(ProjParams in, ProjParams out, const double* __restrict__ inX,
-                                                               const double* __restrict__ inY, const double* __restrict__ outXAxis,
-                                                               const double* __restrict__ outYAxis, uint32_t ox, uint32_t oy,
+                                                               const double* __restrict__ inY, const double* __restrict__ outX,
+                                                               const double* __restrict__ outY, int axes, uint32_t ox, size_t n,
                                                                double deltaX, double deltaY, int outIsLatLong,
                                                                double* __restrict__ matrix)
 {
-    const size_t n = (size_t)ox * oy, stride = (size_t)gridDim.x * kBlock;
+    const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const double outXf = outXAxis[i % ox], outYf = outYAxis[i / ox];
+        const double outXf = axes ? outX[i % ox] : outX[i], outYf = axes ? outY[i / ox] : outY[i];
         double ax = inX[i] + deltaX, ay = inY[i];  // (x + d, y), :343-355
         double bx = inX[i], by = inY[i] + deltaY;  // (x, y + d), :384-396
         transform_point(in, out, ax, ay);
@@ -383,10 +384,71 @@ void launch_vector_reproject_matrix(const char* projIn, const char* projOut, con
         delta = (v > 1) ? v * d : d;
     }
     if (std::fabs(delta) < 1e-9) delta = d;  // :514-518
-    vector_matrix_kernel<<<point_blocks(n), kBlock, 0, stream>>>(in, out, d_inX.get(), d_inY.get(), d_axes.get(), d_axes.get() + ox, (uint32_t)ox,
-                                                                 (uint32_t)oy, delta, delta, out.kind == kLatLong ? 1 : 0, d_matrix);
+    vector_matrix_kernel<<<point_blocks(n), kBlock, 0, stream>>>(in, out, d_inX.get(), d_inY.get(), d_axes.get(), d_axes.get() + ox, 1, (uint32_t)ox,
+                                                                 n, delta, delta, out.kind == kLatLong ? 1 : 0, d_matrix);
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(stream));  // temporaries are released on return
+}
+
+namespace {
+// the delta of mifi_get_vector_reproject_matrix_proj (:458-518) from the positions in the input projection
+double mesh_delta(const double* inX, size_t ox, size_t oy)
+{
+    const double d = 1e-3;
+    double delta;
+    if (ox > 1 && oy > 1) {
+        const size_t ox2 = ox / 2, oy2 = oy / 2;
+        delta = d * (inX[ox + 1] - inX[0]);
+        delta += d * (inX[(oy2 + 1) * ox + ox2 + 1] - inX[oy2 * ox + ox2]);
+        delta /= 2;
+    } else if (ox > 1) {
+        delta = d * (inX[1] - inX[0]);
+    } else if (oy > 1) {
+        delta = d * (inX[ox] - inX[0]);
+    } else {
+        delta = (inX[0] > 1) ? inX[0] * d : d;
+    }
+    return std::fabs(delta) < 1e-9 ? d : delta;
+}
+}  // namespace
+
+// mifi_get_vector_reproject_matrix_field, interpolation.c:657-717: the mesh is given in the INPUT projection
+void launch_vector_reproject_matrix_field(const char* projIn, const char* projOut, const double* h_inX, const double* h_inY, size_t ox,
+                                          size_t oy, double* d_matrix, hipStream_t stream)
+{
+    const ProjParams in = parse_proj4(projIn), out = parse_proj4(projOut);
+    const size_t n = ox * oy;
+    if (n == 0) return;
+    DeviceArray<double> d_in(2 * n), d_out(2 * n);
+    FA_HIP(hipMemcpyAsync(d_in.get(), h_inX, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipMemcpyAsync(d_in.get() + n, h_inY, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipMemcpyAsync(d_out.get(), d_in.get(), 2 * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    project_values_kernel<<<point_blocks(n), kBlock, 0, stream>>>(in, out, d_out.get(), d_out.get() + n, n);  // :696
+    FA_HIP(hipGetLastError());
+    const double delta = mesh_delta(h_inX, ox, oy);
+    vector_matrix_kernel<<<point_blocks(n), kBlock, 0, stream>>>(in, out, d_in.get(), d_in.get() + n, d_out.get(), d_out.get() + n, 0, (uint32_t)ox, n,
+                                                                 delta, delta, out.kind == kLatLong ? 1 : 0, d_matrix);
+    FA_HIP(hipGetLastError());
+    FA_HIP(hipStreamSynchronize(stream));
+}
+
+// mifi_get_vector_reproject_matrix_points, interpolation.c:607-655: a list of points in the OUTPUT projection (m or rad)
+void launch_vector_reproject_matrix_points(const char* projIn, const char* projOut, int inputIsMetric, const double* h_outX,
+                                           const double* h_outY, size_t on, double* d_matrix, hipStream_t stream)
+{
+    const ProjParams in = parse_proj4(projIn), out = parse_proj4(projOut);
+    if (on == 0) return;
+    DeviceArray<double> d_in(2 * on), d_out(2 * on);
+    FA_HIP(hipMemcpyAsync(d_out.get(), h_outX, on * sizeof(double), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipMemcpyAsync(d_out.get() + on, h_outY, on * sizeof(double), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipMemcpyAsync(d_in.get(), d_out.get(), 2 * on * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    project_values_kernel<<<point_blocks(on), kBlock, 0, stream>>>(out, in, d_in.get(), d_in.get() + on, on);  // :635
+    FA_HIP(hipGetLastError());
+    const double delta = inputIsMetric ? 100 : 0.00001;  // :641
+    vector_matrix_kernel<<<point_blocks(on), kBlock, 0, stream>>>(in, out, d_in.get(), d_in.get() + on, d_out.get(), d_out.get() + on, 0, 1, on, delta,
+                                                                  delta, out.kind == kLatLong ? 1 : 0, d_matrix);
+    FA_HIP(hipGetLastError());
+    FA_HIP(hipStreamSynchronize(stream));
 }
 
 int projection_is_degree(const char* proj)

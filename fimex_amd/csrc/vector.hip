@@ -138,6 +138,24 @@ __global__ void __launch_bounds__(kBlock) rotate_direction_vec4(VecArgs a)
     }
 }
 
+// CDMProcessor's direction rotation (src/CDMProcessor.cc:621-636): packed angles are unpacked with ScaleOffset<float>
+// (scale * a + offset in double, stored to the float array), rotated, and packed again with UnScaleOffset<float>
+// ((1 / scale) * (a - offset)) -- three passes there, one here
+__global__ void __launch_bounds__(kBlock) rotate_direction_scaled(VecArgs a, double scale, double invscale, double offset)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.layer) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const double phiDeg = kRadToDeg * a.phi[i];
+    float* p = a.u + (size_t)z0 * a.layer + i;
+    for (uint32_t z = z0; z < z1; ++z, p += a.layer) {
+        const float unpacked = (float)(scale * (double)*p + offset);   // :631
+        const float rotated = rotate_angle(unpacked, phiDeg);          // :632
+        *p = (float)(invscale * ((double)rotated - offset));           // :633
+    }
+}
+
 VecArgs make_args(const fimex_amd_vector_plan& plan, float* u, float* v, size_t oz, uint32_t cellsPerLane, dim3& grid)
 {
     VecArgs a{};
@@ -200,6 +218,16 @@ void launch_vector_direction(const fimex_amd_vector_plan& plan, float* d_angles,
     const VecArgs a = make_args(plan, d_angles, nullptr, oz, vec4 ? 4 : 1, grid);
     if (vec4) rotate_direction_vec4<<<grid, kBlock, 0, stream>>>(a);
     else rotate_direction<<<grid, kBlock, 0, stream>>>(a);
+    FA_HIP(hipGetLastError());
+}
+
+void launch_vector_direction_scaled(const fimex_amd_vector_plan& plan, float* d_angles, size_t oz, double scale, double offset, hipStream_t stream)
+{
+    if (oz == 0) return;
+    FA_REQUIRE(oz <= 0xFFFFFFFFu, "too many slices");
+    dim3 grid;
+    const VecArgs a = make_args(plan, d_angles, nullptr, oz, 1, grid);
+    rotate_direction_scaled<<<grid, kBlock, 0, stream>>>(a, scale, 1 / scale, offset);  // UnScaleOffset's invscale_ = 1 / scale (:464)
     FA_HIP(hipGetLastError());
 }
 

@@ -217,6 +217,12 @@ int fimex_amd_regrid_slice_host(const fimex_amd_regrid_plan* plan, const float* 
 int fimex_amd_bad2nan_device(float* d_data, size_t n, float badVal, void* stream);
 int fimex_amd_nan2bad_device(float* d_data, size_t n, float badVal, void* stream);
 
+/** CDMProcessor's direction rotation of packed angles (src/CDMProcessor.cc:621-636): scale * a + offset, rotate
+ *  (a9), (a - offset) / scale, in one pass; angles [oz][oy][ox] in place. */
+int fimex_amd_vector_reproject_direction_scaled_host(const fimex_amd_vector_plan* plan, float* angles, size_t size, double scale, double offset);
+int fimex_amd_vector_reproject_direction_scaled_device(const fimex_amd_vector_plan* plan, float* d_angles, size_t oz, double scale,
+                                                       double offset, void* stream);
+
 /* ------------------------------------------------ typed slices */
 /** CDMDataType, include/fimex/CDMDataType.h:35-49 (same values). */
 typedef enum fimex_amd_datatype {
@@ -245,6 +251,13 @@ int fimex_amd_regrid_slice_typed_host(const fimex_amd_regrid_plan* plan, const v
                                       const fimex_amd_vector_plan* vec, int isXComponent,
                                       const fimex_amd_process2d* post, size_t nPost,
                                       void* outData, size_t outCapacity, size_t* newSize);
+
+/** CDMProcessor::getDataSlice's vector rotation on stored types (src/CDMProcessor.cc:590-618): both components become
+ *  float/NaN (data2InterpolationArray), are rotated in place (a8), and the requested one (returnX != 0: x) comes back in
+ *  outType with outFill as interpolationArray2Data does.  size elements per component, [size/(ox*oy)][oy][ox]. */
+int fimex_amd_rotate_vector_typed_host(const fimex_amd_vector_plan* plan, const void* xData, int xType, double xFill,
+                                       const void* yData, int yType, double yFill, size_t size, int returnX,
+                                       int outType, double outFill, void* outData);
 
 /* ------------------------------------------------------- plan build helpers */
 /** mifi_points2position, include/fimex/interpolation.h:415, src/interpolation.c:148-217:
@@ -292,6 +305,14 @@ int fimex_amd_get_vector_reproject_matrix_host(const char* proj_input, const cha
 int fimex_amd_get_vector_reproject_matrix_device(const char* proj_input, const char* proj_output, const double* out_x_axis,
                                                  const double* out_y_axis, int out_x_axis_type, int out_y_axis_type,
                                                  size_t ox, size_t oy, double* d_matrix, void* stream);
+/** mifi_get_vector_reproject_matrix_field, src/interpolation.c:657-717: the [oy][ox] mesh is given as two fields in the
+ *  INPUT projection (CDMProcessor's rotation to lat/lon, src/CDMProcessor.cc:123-136). */
+int fimex_amd_get_vector_reproject_matrix_field_host(const char* proj_input, const char* proj_output, const double* in_x_field,
+                                                     const double* in_y_field, size_t ox, size_t oy, double* matrix);
+/** mifi_get_vector_reproject_matrix_points, src/interpolation.c:607-655: on points in the OUTPUT projection (m or rad),
+ *  finite difference of 100 m (inputIsMetric) or 1e-5 rad. */
+int fimex_amd_get_vector_reproject_matrix_points_host(const char* proj_input, const char* proj_output, int inputIsMetric,
+                                                      const double* out_x_points, const double* out_y_points, size_t on, double* matrix);
 /** Projection::isDegree (src/coordSys/Projection.cc): 1 for geographic and rotated lat/lon strings, 0 otherwise, -1 on error. */
 int fimex_amd_projection_is_degree(const char* proj);
 

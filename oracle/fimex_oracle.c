@@ -24,6 +24,9 @@
  *     (result implementation-defined).
  *  D5 fill2d / creepfill on slices with nx < 2 or ny < 2 return ORC_ERROR when
  *     there is something to fill (the reference reads out of bounds).
+ *  D6 float -> integer conversion of values beyond the range of long: lround is
+ *     unspecified there; LONG_MIN (glibc, x86-64) is kept, then truncated to int
+ *     as MetNoFimex::round does (include/fimex/Utils.h:72-75).
  */
 #include "fimex_oracle.h"
 

@@ -150,3 +150,55 @@ def test_quarter_turn_rotates_u_into_v(fa):
     np.testing.assert_allclose(np.ravel(gu), np.ravel(wu), atol=1e-4); np.testing.assert_allclose(np.ravel(gv), np.ravel(wv), atol=1e-4)
     np.testing.assert_allclose(np.hypot(np.ravel(gu), np.ravel(gv)), np.hypot(u, v), rtol=1e-5)
     np.testing.assert_allclose(np.ravel(gu), v, atol=1e-4)  # u' = v, v' = -u for this turn (testInterpolation.cc:441-447)
+
+
+def test_matrix_from_a_field_in_the_input_projection(fa):
+    """mifi_get_vector_reproject_matrix_field (CDMProcessor's rotation to lat/lon): the mesh of the grid's own axes."""
+    from test_oracle_kats import _rotation_matrix_field
+    xa, ya = np.linspace(-8e5, 8e5, 41), np.linspace(-6e5, 7e5, 29)
+    xx, yy = np.meshgrid(xa, ya)
+    got = fa.get_vector_reproject_matrix_field_host(STERE_OBL, GEO, xx, yy).reshape(-1, 4)
+    ox, oy = po.transform(STERE_OBL, GEO, xx.ravel(), yy.ravel())
+    want = _rotation_matrix_field(STERE_OBL, GEO, xx.ravel(), yy.ravel(), ox, oy, xa.size, ya.size).reshape(-1, 4)
+    np.testing.assert_allclose(got[:, :3], want[:, :3], atol=2e-6)
+
+
+def test_matrix_at_points(fa):
+    """mifi_get_vector_reproject_matrix_points: fixed 100 m / 1e-5 rad differences."""
+    rng = np.random.default_rng(8)
+    lon, lat = np.radians(rng.uniform(-20, 40, 500)), np.radians(rng.uniform(45, 80, 500))
+    got = fa.get_vector_reproject_matrix_points_host(STERE, GEO, True, lon, lat).reshape(-1, 4)
+    ix, iy = po.transform(GEO, STERE, lon, lat)
+    xdx = po.transform(STERE, GEO, ix + 100, iy)
+    ydy = po.transform(STERE, GEO, ix, iy + 100)
+    want = oracle.vector_matrix_from_deltas(lon, lat, xdx, ydy, 100., 100., True).reshape(-1, 4)
+    np.testing.assert_allclose(got[:, :3], want[:, :3], atol=1e-7)
+
+
+def test_rotate_vector_on_stored_types_and_packed_directions(fa):
+    """src/CDMProcessor.cc:590-636: both components from their stored types, the requested one back in its type; directions
+    stored as short with scale_factor 0.1 unpacked, rotated and packed again."""
+    ox, oy, oz = 37, 23, 3
+    m = cases.rotation_matrix(ox, oy, seed=3)
+    vec = fa.VectorPlan(m, ox, oy)
+    rng = np.random.default_rng(4)
+    x = rng.integers(-3000, 3000, (oz, oy, ox)).astype(np.int16)
+    y = rng.normal(0, 12, (oz, oy, ox)).astype(np.float32)
+    x.reshape(-1)[rng.choice(x.size, 40, replace=False)] = -32767
+    y.reshape(-1)[rng.choice(y.size, 40, replace=False)] = np.float32(9.96921e36)
+    fx, fy = oracle.data2interpolation_array(x, -32767.0), oracle.data2interpolation_array(y, 9.96921e36)
+    ru, rv = oracle.vector_reproject_values(m, fx, fy, ox, oy)
+    gx = fa.rotate_vector_typed_host(vec, x, -32767.0, y, 9.96921e36, returnX=True)
+    gy = fa.rotate_vector_typed_host(vec, x, -32767.0, y, 9.96921e36, returnX=False)
+    assert np.array_equal(gx, oracle.interpolation_array2data(ru, oracle.CDM_SHORT, -32767.0).reshape(gx.shape))
+    wy = oracle.interpolation_array2data(rv, oracle.CDM_FLOAT, 9.96921e36).reshape(gy.shape)
+    assert np.array_equal(gy.view(np.uint32), wy.view(np.uint32))
+    # packed directions
+    ang = rng.integers(0, 3600, (oz, oy, ox)).astype(np.float32)
+    ang[0, 0, :5] = np.nan
+    scale, offset = 0.1, 5.0
+    unpacked = (scale * ang.astype(np.float64) + offset).astype(np.float32)
+    rotated = oracle.vector_reproject_direction(m, unpacked, ox, oy)
+    want = ((1 / scale) * (rotated.astype(np.float64) - offset)).astype(np.float32)
+    got = vec.reproject_direction_scaled_host(ang, scale, offset)
+    assert cases.same(got, want.reshape(got.shape)), cases.describe_mismatch(got, want.reshape(got.shape))

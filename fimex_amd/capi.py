@@ -100,6 +100,11 @@ SYMBOLS = {
     "fimex_amd_rotate_vector_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_double, _V, ctypes.c_int, ctypes.c_double, _Z, ctypes.c_int,
                                                           ctypes.c_int, ctypes.c_double, _V]),
     "fimex_amd_projection_is_degree": (ctypes.c_int, [ctypes.c_char_p]),
+    "fimex_amd_coord_nearest_host": (ctypes.c_int, [_D, _D, _Z, _D, _D, _Z, _Z]),
+    "fimex_amd_coord_nearest_device": (ctypes.c_int, [_V, _V, _Z, _V, _V, _Z, _Z, _V]),
+    "fimex_amd_coord_kdtree_host": (ctypes.c_int, [ctypes.c_double, _D, _D, _Z, _D, _D, _Z, _Z]),
+    "fimex_amd_coord_kdtree_device": (ctypes.c_int, [ctypes.c_double, _V, _V, _Z, _V, _V, _Z, _Z, _V]),
+    "fimex_amd_grid_distance_host": (ctypes.c_int, [_D, _D, _Z, _Z, _D]),
     "fimex_amd_scan_sum_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _ZP, _V]),
 }
 
@@ -455,6 +460,32 @@ def projection_is_degree(proj):
     if r < 0:
         raise FimexAmdError(load().fimex_amd_last_error().decode() or "fimex_amd call failed")
     return bool(r)
+
+
+def coord_nearest_host(lonPoints, latPoints, lonVals, latVals):
+    """MIFI_INTERPOL_COORD_NN plan: (x index, y index) of the closest source cell per target point, -1 where none."""
+    px, py = _f64(lonPoints).copy().ravel(), _f64(latPoints).copy().ravel()
+    lo, la = _f64(lonVals), _f64(latVals)
+    orgY, orgX = lo.shape
+    _check(load().fimex_amd_coord_nearest_host(_dp(px), _dp(py), px.size, _dp(lo.reshape(-1)), _dp(la.reshape(-1)), orgX, orgY))
+    return px, py
+
+
+def coord_kdtree_host(maxDist, lonPoints, latPoints, lonVals, latVals):
+    """MIFI_INTERPOL_COORD_NN_KD plan: closest source cell within maxDist metres, -1000 where none."""
+    px, py = _f64(lonPoints).copy().ravel(), _f64(latPoints).copy().ravel()
+    lo, la = _f64(lonVals), _f64(latVals)
+    orgY, orgX = lo.shape
+    _check(load().fimex_amd_coord_kdtree_host(maxDist, _dp(px), _dp(py), px.size, _dp(lo.reshape(-1)), _dp(la.reshape(-1)), orgX, orgY))
+    return px, py
+
+
+def grid_distance_host(lonVals, latVals):
+    lo, la = _f64(lonVals), _f64(latVals)
+    orgY, orgX = lo.shape
+    out = ctypes.c_double(0)
+    _check(load().fimex_amd_grid_distance_host(_dp(lo.reshape(-1)), _dp(la.reshape(-1)), orgX, orgY, ctypes.byref(out)))
+    return out.value
 
 
 def scan_sum_device(d_values, n, mode=0, average=0.0, algo=1, stream=0):

@@ -801,6 +801,89 @@ int fimex_amd_projection_is_degree(const char* proj)
     return rc == FIMEX_AMD_OK ? r : -1;
 }
 
+}  // extern "C"
+
+namespace {
+template <typename F>
+void coord_search_host(double* px, double* py, size_t nPoints, const double* lon, const double* lat, size_t orgX, size_t orgY, F&& run)
+{
+    const size_t n = orgX * orgY;
+    FA_REQUIRE(nPoints == 0 || (px != nullptr && py != nullptr), "NULL argument");
+    FA_REQUIRE(n == 0 || (lon != nullptr && lat != nullptr), "NULL argument");
+    (void)current_device_checked();
+    ScopedStream stream;
+    DeviceArray<double> d_q(2 * nPoints), d_src(2 * n);
+    if (nPoints) {
+        FA_HIP(hipMemcpyAsync(d_q.get(), px, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        FA_HIP(hipMemcpyAsync(d_q.get() + nPoints, py, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+    }
+    if (n) {
+        FA_HIP(hipMemcpyAsync(d_src.get(), lon, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        FA_HIP(hipMemcpyAsync(d_src.get() + n, lat, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+    }
+    run(d_q.get(), d_q.get() + nPoints, d_src.get(), d_src.get() + n, stream.get());
+    if (nPoints) {
+        FA_HIP(hipMemcpyAsync(px, d_q.get(), nPoints * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+        FA_HIP(hipMemcpyAsync(py, d_q.get() + nPoints, nPoints * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+    }
+    stream.sync();
+}
+}  // namespace
+
+extern "C" {
+
+int fimex_amd_coord_nearest_host(double* px, double* py, size_t nPoints, const double* lon, const double* lat, size_t orgX, size_t orgY)
+{
+    return c_guard([&] {
+        coord_search_host(px, py, nPoints, lon, lat, orgX, orgY, [&](double* qx, double* qy, const double* dlon, const double* dlat, hipStream_t st) {
+            launch_coord_nearest(qx, qy, nPoints, dlon, dlat, orgX, orgY, st);
+        });
+    });
+}
+
+int fimex_amd_coord_nearest_device(double* d_px, double* d_py, size_t nPoints, const double* d_lon, const double* d_lat, size_t orgX, size_t orgY,
+                                   void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(nPoints == 0 || (d_px != nullptr && d_py != nullptr && d_lon != nullptr && d_lat != nullptr), "NULL device buffer");
+        (void)current_device_checked();
+        launch_coord_nearest(d_px, d_py, nPoints, d_lon, d_lat, orgX, orgY, as_stream(stream));
+    });
+}
+
+int fimex_amd_coord_kdtree_host(double maxDist, double* px, double* py, size_t nPoints, const double* lon, const double* lat, size_t orgX, size_t orgY)
+{
+    return c_guard([&] {
+        coord_search_host(px, py, nPoints, lon, lat, orgX, orgY, [&](double* qx, double* qy, const double* dlon, const double* dlat, hipStream_t st) {
+            launch_coord_kdtree(maxDist, qx, qy, nPoints, dlon, dlat, orgX, orgY, st);
+        });
+    });
+}
+
+int fimex_amd_coord_kdtree_device(double maxDist, double* d_px, double* d_py, size_t nPoints, const double* d_lon, const double* d_lat, size_t orgX,
+                                  size_t orgY, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(nPoints == 0 || (d_px != nullptr && d_py != nullptr && d_lon != nullptr && d_lat != nullptr), "NULL device buffer");
+        (void)current_device_checked();
+        launch_coord_kdtree(maxDist, d_px, d_py, nPoints, d_lon, d_lat, orgX, orgY, as_stream(stream));
+    });
+}
+
+int fimex_amd_grid_distance_host(const double* lon, const double* lat, size_t orgX, size_t orgY, double* maxGridDistance)
+{
+    return c_guard([&] {
+        const size_t n = orgX * orgY;
+        FA_REQUIRE(n > 0 && lon != nullptr && lat != nullptr && maxGridDistance != nullptr, "NULL or empty argument");
+        (void)current_device_checked();
+        ScopedStream stream;
+        DeviceArray<double> d(2 * n);
+        FA_HIP(hipMemcpyAsync(d.get(), lon, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        FA_HIP(hipMemcpyAsync(d.get() + n, lat, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        *maxGridDistance = grid_distance(d.get(), d.get() + n, orgX, orgY, stream.get());
+    });
+}
+
 int fimex_amd_scan_sum_device(const float* d_values, size_t n, int mode, double average, int algo, double* sum, size_t* nUndefined, void* stream)
 {
     return c_guard([&] {

@@ -114,6 +114,13 @@ void launch_vector_reproject_matrix_points(const char* projIn, const char* projO
                                            const double* h_outY, size_t on, double* d_matrix, hipStream_t stream);
 int projection_is_degree(const char* proj);
 
+// coordsearch.hip: coordinate-based nearest neighbour plans
+double grid_distance(const double* d_lon, const double* d_lat, size_t orgX, size_t orgY, hipStream_t stream);
+void launch_coord_nearest(double* d_pointsX, double* d_pointsY, size_t nPoints, const double* d_lon, const double* d_lat, size_t orgX,
+                          size_t orgY, hipStream_t stream);
+void launch_coord_kdtree(double maxDist, double* d_pointsX, double* d_pointsY, size_t nPoints, const double* d_lon, const double* d_lat,
+                         size_t orgX, size_t orgY, hipStream_t stream);
+
 // fill.hip
 void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
                 size_t* h_nChanged, hipStream_t stream);

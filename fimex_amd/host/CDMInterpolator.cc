@@ -1,5 +1,6 @@
 #include "CDMInterpolator.h"
 
+#include <algorithm>
 #include <cmath>
 #include <iostream>
 #include <limits>
@@ -57,9 +58,8 @@ void CDMInterpolator::changeProjection(int method, const std::string& proj_input
         break;
     case MIFI_INTERPOL_COORD_NN:
     case MIFI_INTERPOL_COORD_NN_KD:
-        // the coordinate search that builds these plans (src/CDMInterpolator.cc:992-1220) is not part of this round;
-        // plans built elsewhere apply through CachedInterpolation as in the reference
-        throw CDMException("coord_nearestneighbor / coord_kdtree plan construction is not implemented");
+        changeProjectionByCoordinates(method, proj_input, out_x_axis, out_y_axis, xDeg, yDeg);
+        break;
     case MIFI_INTERPOL_FORWARD_SUM: case MIFI_INTERPOL_FORWARD_MEAN: case MIFI_INTERPOL_FORWARD_MEDIAN:
     case MIFI_INTERPOL_FORWARD_MAX: case MIFI_INTERPOL_FORWARD_MIN: case MIFI_INTERPOL_FORWARD_UNDEF_SUM:
     case MIFI_INTERPOL_FORWARD_UNDEF_MEAN: case MIFI_INTERPOL_FORWARD_UNDEF_MEDIAN: case MIFI_INTERPOL_FORWARD_UNDEF_MAX:
@@ -108,6 +108,58 @@ void CDMInterpolator::changeProjectionByProjectionParameters(int method, const s
     std::copy(matrix_.begin(), matrix_.end(), m.get());
     cachedVectorReprojection_ =
         std::make_shared<CachedVectorReprojection>(MIFI_VECTOR_KEEP_SIZE, m, (int)outXAxis.size(), (int)outYAxis.size());
+}
+
+// src/CDMInterpolator.cc:304-326
+double CDMInterpolator::getMaxDistanceOfInterest(const std::vector<double>& out_x_axis, const std::vector<double>& out_y_axis, bool isMetric) const
+{
+    if (maxDistance_ > 0) return maxDistance_;
+    // the largest step of the output axes (as given, the reference does not convert degrees here) is the region of influence
+    const double factor = isMetric ? 1. : 6371000.;  // MIFI_EARTH_RADIUS_M
+    double maxX = 0, maxY = 0;
+    for (size_t i = 0; i + 1 < out_x_axis.size(); ++i) maxX = std::max(factor * std::fabs(out_x_axis[i + 1] - out_x_axis[i]), maxX);
+    for (size_t j = 0; j + 1 < out_y_axis.size(); ++j) maxY = std::max(factor * std::fabs(out_y_axis[j + 1] - out_y_axis[j]), maxY);
+    return std::max(maxX, maxY);
+}
+
+// src/CDMInterpolator.cc:1335-1420
+void CDMInterpolator::changeProjectionByCoordinates(int method, const std::string& proj_input, const std::vector<double>& out_x_axis,
+                                                    const std::vector<double>& out_y_axis, bool xDegree, bool yDegree)
+{
+    const std::vector<double> orgX = dataReader_->xAxis(), orgY = dataReader_->yAxis();
+    std::vector<double> lonVals, latVals;
+    if (dataReader_->lonLat(lonVals, latVals)) {  // 2-D longitude / latitude variables, degrees (:1347-1357)
+        if (lonVals.size() != orgX.size() * orgY.size() || latVals.size() != lonVals.size())
+            throw CDMException("longitude / latitude fields do not match the grid");
+    } else if (isDegreeProjection(dataReader_->projString())) {  // lonLatVals2Matrix (:1376-1380)
+        lonVals.resize(orgX.size() * orgY.size());
+        latVals.resize(lonVals.size());
+        for (size_t j = 0; j < orgY.size(); ++j)
+            for (size_t i = 0; i < orgX.size(); ++i) { lonVals[j * orgX.size() + i] = orgX[i]; latVals[j * orgX.size() + i] = orgY[j]; }
+    } else {
+        throw CDMException("coordinate interpolation needs longitude and latitude of the source grid");
+    }
+    toRad(lonVals);
+    toRad(latVals);
+    std::vector<double> outXAxis = out_x_axis, outYAxis = out_y_axis;
+    bool isMetric = true;
+    if (xDegree) { isMetric = false; toRad(outXAxis); }  // :1386-1393
+    if (yDegree) toRad(outYAxis);
+    projectAxesAmd(proj_input, LAT_LON_PROJSTR, outXAxis, outYAxis, pointsOnXAxis_, pointsOnYAxis_);  // :1399
+    if (method == MIFI_INTERPOL_COORD_NN) {
+        checkAmd(fimex_amd_coord_nearest_host(pointsOnXAxis_.data(), pointsOnYAxis_.data(), pointsOnXAxis_.size(), lonVals.data(), latVals.data(),
+                                              orgX.size(), orgY.size()),
+                 "fastTranslatePointsToClosestInputCell");
+    } else {
+        const double maxDistance = getMaxDistanceOfInterest(out_x_axis, out_y_axis, isMetric);  // :1407
+        checkAmd(fimex_amd_coord_kdtree_host(maxDistance, pointsOnXAxis_.data(), pointsOnYAxis_.data(), pointsOnXAxis_.size(), lonVals.data(),
+                                             latVals.data(), orgX.size(), orgY.size()),
+                 "flannTranslatePointsToClosestInputCell");
+    }
+    cachedInterpolation_ = std::make_shared<CachedInterpolation>(dataReader_->xDimName(), dataReader_->yDimName(), method, pointsOnXAxis_,
+                                                                 pointsOnYAxis_, orgX.size(), orgY.size(), out_x_axis.size(), out_y_axis.size());
+    cachedVectorReprojection_.reset();  // "vector data found, but not possible? to interpolate with coordinate-interpolation" (:1418)
+    matrix_.clear();
 }
 
 // src/CDMInterpolator.cc:1242-1333

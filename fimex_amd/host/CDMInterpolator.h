@@ -72,6 +72,10 @@ public:
     // (:115-119) and interpolationArray2Data (:121-124) included, only typed elements cross PCIe
     TypedData getTypedDataSlice(const std::string& varName, size_t unLimDimPos);
 
+    // include/fimex/CDMInterpolator.h:246-252: radius (m) of the coord_kdtree search; <= 0: derived from the output axes
+    void setDistanceOfInterest(double dist) { maxDistance_ = dist; }
+    double getMaxDistanceOfInterest(const std::vector<double>& out_x_axis, const std::vector<double>& out_y_axis, bool isMetric) const;
+
     void addPreprocess(std::shared_ptr<InterpolatorProcess2d> process) { preprocesses_.push_back(process); }
     void addPostprocess(std::shared_ptr<InterpolatorProcess2d> process) { postprocesses_.push_back(process); }
 
@@ -88,9 +92,12 @@ private:
     std::shared_ptr<CachedInterpolationInterface> cachedInterpolation_;
     std::shared_ptr<CachedVectorReprojection> cachedVectorReprojection_;
     std::vector<double> pointsOnXAxis_, pointsOnYAxis_, matrix_;
+    double maxDistance_ = -1;  // src/CDMInterpolator.cc:103
 
     void changeProjectionByProjectionParameters(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                 std::vector<double> outYAxis, bool xDegree, bool yDegree);
+    void changeProjectionByCoordinates(int method, const std::string& proj_input, const std::vector<double>& out_x_axis,
+                                       const std::vector<double>& out_y_axis, bool xDegree, bool yDegree);
     void changeProjectionByForwardInterpolation(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                 std::vector<double> outYAxis, bool xDegree, bool yDegree);
     shared_array<float> readInput(const std::string& varName, size_t unLimDimPos, size_t& size) const;

@@ -8,6 +8,7 @@
 //   var <name> <levels> <file [steps][levels][ny][nx]> <fill|nan> [vector <counterpart> <x|y>] [type <char|short|int|float|double|uchar|ushort|uint|int64|uint64>]
 //       (the file holds elements of that type, float by default)
 //   method <name>                 outproj <proj4>
+//   lon2d|lat2d <file of doubles [ny][nx], degrees>   (coord_nearestneighbor / coord_kdtree / forward_*)   maxdist <metres>
 //   outx <file of doubles> <unit> outy <file of doubles> <unit>
 //   pre|post fill2d <relaxCrit> <corrEff> <maxLoop> | creepfill2d <repeat> <weight> | creepfillval2d <repeat> <weight> <default>
 //   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32 for float variables, .raw in the stored type otherwise)
@@ -50,6 +51,14 @@ public:
     std::vector<double> x, y;
     std::map<std::string, VariableInfo> vars;
     std::map<std::string, std::vector<unsigned char>> data;  // raw elements of the variable's type
+    std::vector<double> lon2d, lat2d;                         // optional 2-D coordinates, degrees, [ny][nx]
+    bool lonLat(std::vector<double>& lon, std::vector<double>& lat) const override
+    {
+        if (lon2d.empty() || lat2d.empty()) return false;
+        lon = lon2d;
+        lat = lat2d;
+        return true;
+    }
     std::string projString() const override { return proj; }
     std::vector<double> xAxis() const override { return x; }
     std::vector<double> yAxis() const override { return y; }
@@ -127,6 +136,7 @@ int main(int argc, char** argv)
         const std::string outDir = argv[2];
         std::string line, method, outproj, outxUnit, outyUnit;
         std::vector<double> outx, outy;
+        double maxDist = -1;
         std::vector<std::pair<std::string, size_t>> gets;
         std::vector<std::pair<bool, std::shared_ptr<InterpolatorProcess2d>>> procs;
         while (std::getline(spec, line)) {
@@ -137,6 +147,9 @@ int main(int argc, char** argv)
             else if (key == "outproj") { std::getline(in, outproj); }
             else if (key == "xaxis") { std::string f; in >> f; reader->x = readAll<double>(f); }
             else if (key == "yaxis") { std::string f; in >> f; reader->y = readAll<double>(f); }
+            else if (key == "lon2d") { std::string f; in >> f; reader->lon2d = readAll<double>(f); }
+            else if (key == "lat2d") { std::string f; in >> f; reader->lat2d = readAll<double>(f); }
+            else if (key == "maxdist") { in >> maxDist; }
             else if (key == "outx") { std::string f; in >> f >> outxUnit; outx = readAll<double>(f); }
             else if (key == "outy") { std::string f; in >> f >> outyUnit; outy = readAll<double>(f); }
             else if (key == "method") { in >> method; }
@@ -175,6 +188,7 @@ int main(int argc, char** argv)
         for (auto& p : procs) { if (p.first) interp.addPreprocess(p.second); else interp.addPostprocess(p.second); }
         const int m = mifi_string_to_interpolation_method(method.c_str());
         if (m == MIFI_INTERPOL_UNKNOWN) throw CDMException("unknown method " + method);
+        interp.setDistanceOfInterest(maxDist);
         interp.changeProjection(m, outproj, outx, outy, outxUnit, outyUnit);
         writeAll(outDir + "/points_x.f64", interp.pointsOnXAxis().data(), interp.pointsOnXAxis().size());
         writeAll(outDir + "/points_y.f64", interp.pointsOnYAxis().data(), interp.pointsOnYAxis().size());

@@ -316,6 +316,25 @@ int fimex_amd_get_vector_reproject_matrix_points_host(const char* proj_input, co
 /** Projection::isDegree (src/coordSys/Projection.cc): 1 for geographic and rotated lat/lon strings, 0 otherwise, -1 on error. */
 int fimex_amd_projection_is_degree(const char* proj);
 
+/* ------------------------------- coordinate-based nearest neighbour plans (8f n3) */
+/** fastTranslatePointsToClosestInputCell with getGridDistance, src/CDMInterpolator.cc:1069-1217 (MIFI_INTERPOL_COORD_NN):
+ *  pointsOnXAxis / pointsOnYAxis hold longitude / latitude (rad) of every target cell on entry and the x / y index of the
+ *  closest source cell (as doubles, -1 when none lies within the grid's region of influence) on return; lonVals / latVals:
+ *  the source grid's coordinates in rad, [orgYDimSize][orgXDimSize], NaN = undefined.  The result is the plan of
+ *  fimex_amd_regrid_plan_create(MIFI_INTERPOL_COORD_NN, ...). */
+int fimex_amd_coord_nearest_host(double* pointsOnXAxis, double* pointsOnYAxis, size_t nPoints,
+                                 const double* lonVals, const double* latVals, size_t orgXDimSize, size_t orgYDimSize);
+int fimex_amd_coord_nearest_device(double* d_pointsOnXAxis, double* d_pointsOnYAxis, size_t nPoints,
+                                   const double* d_lonVals, const double* d_latVals, size_t orgXDimSize, size_t orgYDimSize, void* stream);
+/** flannTranslatePointsToClosestInputCell, src/CDMInterpolator.cc:991-1067 (MIFI_INTERPOL_COORD_NN_KD): closest source
+ *  cell within maxDist metres (chord on a sphere of MIFI_EARTH_RADIUS_M), -1000 when none. */
+int fimex_amd_coord_kdtree_host(double maxDist, double* pointsOnXAxis, double* pointsOnYAxis, size_t nPoints,
+                                const double* lonVals, const double* latVals, size_t orgXDimSize, size_t orgYDimSize);
+int fimex_amd_coord_kdtree_device(double maxDist, double* d_pointsOnXAxis, double* d_pointsOnYAxis, size_t nPoints,
+                                  const double* d_lonVals, const double* d_latVals, size_t orgXDimSize, size_t orgYDimSize, void* stream);
+/** getGridDistance, src/CDMInterpolator.cc:1069-1141: the region of influence (rad) COORD_NN derives from the source grid. */
+int fimex_amd_grid_distance_host(const double* lonVals, const double* latVals, size_t orgXDimSize, size_t orgYDimSize, double* maxGridDistance);
+
 /* ------------------------------------------------------------- diagnostics */
 /** The scan-order double sums the fills start with (src/interpolation.c:1256-1264 sum of the defined values, mode 0;
  *  :1288-1299 sum of |v - average|, mode 1; mode 2 only counts), on n device floats: exactly the value the reference's

@@ -77,6 +77,12 @@ def _declare(L):
     L.orc_bad2nanf.restype = _Z
     L.orc_nanf2bad.argtypes = [_F, _F, ctypes.c_float]
     L.orc_nanf2bad.restype = _Z
+    L.orc_get_grid_distance.argtypes = [_D, _D, _Z, _Z]
+    L.orc_get_grid_distance.restype = ctypes.c_double
+    L.orc_fast_translate_points.argtypes = [_D, _D, _Z, _D, _D, _Z, _Z]
+    L.orc_fast_translate_points.restype = ctypes.c_int
+    L.orc_flann_translate_points.argtypes = [ctypes.c_double, _D, _D, _Z, _D, _D, _Z, _Z]
+    L.orc_flann_translate_points.restype = ctypes.c_int
     L.orc_get_values_1d_f.argtypes = [ctypes.c_int, _F, _F, _F, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     L.orc_get_values_1d_f.restype = ctypes.c_int
     L.orc_get_values_linear_d.argtypes = [_D, _D, _D, _Z, ctypes.c_double, ctypes.c_double, ctypes.c_double]
@@ -270,6 +276,27 @@ def get_values_linear_d(fieldA, fieldB, a, b, x):
     out = np.empty(A.shape)
     assert lib().orc_get_values_linear_d(_d(A.reshape(-1)), _d(B.reshape(-1)), _d(out.reshape(-1)), A.size, a, b, x) == OK
     return out
+
+
+def grid_distance(lonVals, latVals):
+    lo, la = np.ascontiguousarray(lonVals, np.float64), np.ascontiguousarray(latVals, np.float64)
+    return lib().orc_get_grid_distance(_d(lo.reshape(-1)), _d(la.reshape(-1)), lo.shape[1], lo.shape[0])
+
+
+def fast_translate_points(lonPoints, latPoints, lonVals, latVals):
+    """COORD_NN: (x, y) index of the closest source cell per point, -1 where none."""
+    px, py = np.array(lonPoints, np.float64).ravel(), np.array(latPoints, np.float64).ravel()
+    lo, la = np.ascontiguousarray(lonVals, np.float64), np.ascontiguousarray(latVals, np.float64)
+    assert lib().orc_fast_translate_points(_d(px), _d(py), px.size, _d(lo.reshape(-1)), _d(la.reshape(-1)), lo.shape[1], lo.shape[0]) == OK
+    return px, py
+
+
+def flann_translate_points(maxDist, lonPoints, latPoints, lonVals, latVals):
+    """COORD_NN_KD: closest source cell within maxDist metres, -1000 where none."""
+    px, py = np.array(lonPoints, np.float64).ravel(), np.array(latPoints, np.float64).ravel()
+    lo, la = np.ascontiguousarray(lonVals, np.float64), np.ascontiguousarray(latVals, np.float64)
+    assert lib().orc_flann_translate_points(maxDist, _d(px), _d(py), px.size, _d(lo.reshape(-1)), _d(la.reshape(-1)), lo.shape[1], lo.shape[0]) == OK
+    return px, py
 
 
 def nan2bad(a, bad):

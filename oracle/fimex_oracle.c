@@ -787,3 +787,127 @@ int orc_get_values_linear_d(const double* A, const double* B, double* out, size_
     else for (size_t i = 0; i < n; ++i) out[i] = A[i] + f * (B[i] - A[i]);
     return ORC_OK;
 }
+
+/* -------------------------------------- coordinate-based nearest neighbour plans (n3) */
+/* getGridDistance, src/CDMInterpolator.cc:1069-1141 */
+double orc_get_grid_distance(const double* lonVals, const double* latVals, size_t orgX, size_t orgY)
+{
+    const size_t n = orgX * orgY;
+    size_t steps, stepSize;
+    if (n > 1000) { steps = 53; stepSize = n / steps; } else { stepSize = 1; steps = n; }
+    double minOfMax = 2;
+    int any = 0;
+    for (size_t ik = 0; ik < steps; ++ik) {
+        const size_t samplePos = ik * stepSize;
+        const double lon0 = lonVals[samplePos], lat0 = latVals[samplePos];
+        if (isnan(lon0) || isnan(lat0)) continue;
+        double min_cos_d = -2;
+        for (size_t pos = 0; pos < n; ++pos) {
+            if (pos == samplePos) continue;
+            const double lon1 = lonVals[pos], lat1 = latVals[pos];
+            if (isnan(lon1) || isnan(lat1)) continue;
+            const double dlon = lon0 - lon1;
+            const double cos_d = cos(lat0) * cos(lat1) * cos(dlon) + sin(lat0) * sin(lat1); /* :1103 */
+            if (cos_d > min_cos_d) min_cos_d = cos_d;
+        }
+        if (min_cos_d < minOfMax) minOfMax = min_cos_d; /* min_element of the samples :1136 */
+        any = 1;
+    }
+    if (!any) return nan("");
+    double d = acos(minOfMax);
+    d *= 1.414;
+    if (d > ORC_PI) d = ORC_PI;
+    return d;
+}
+
+typedef struct { double lat, lon, x, y; } orc_ll_point;
+static int orc_ll_cmp(const void* a, const void* b)
+{
+    const double la = ((const orc_ll_point*)a)->lat, lb = ((const orc_ll_point*)b)->lat;
+    return (la > lb) - (la < lb);
+}
+
+/* fastTranslatePointsToClosestInputCell, :1158-1217: latitude-sorted list, walk up and down from the query's latitude
+ * while the latitude difference alone does not exceed the best distance so far.  (qsort instead of std::sort: the order
+ * of cells with equal latitude is unspecified in both.) */
+int orc_fast_translate_points(double* pointsX, double* pointsY, size_t nPoints, const double* lonVals, const double* latVals, size_t orgX, size_t orgY)
+{
+    const double max_grid_d = orc_get_grid_distance(lonVals, latVals, orgX, orgY);
+    if (isnan(max_grid_d)) return ORC_ERROR;
+    const double min_grid_cos_d = cos(max_grid_d);
+    orc_ll_point* ll = (orc_ll_point*)malloc((orgX * orgY + 1) * sizeof(orc_ll_point));
+    if (!ll) return ORC_ERROR;
+    size_t m = 0;
+    for (size_t ix = 0; ix < orgX; ++ix)
+        for (size_t iy = 0; iy < orgY; ++iy) { /* :1169-1176, x-major as the reference */
+            const size_t pos = ix + iy * orgX;
+            if (!(isnan(lonVals[pos]) || isnan(latVals[pos]))) {
+                ll[m].lat = latVals[pos]; ll[m].lon = lonVals[pos]; ll[m].x = (double)ix; ll[m].y = (double)iy; ++m;
+            }
+        }
+    qsort(ll, m, sizeof(orc_ll_point), orc_ll_cmp);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long i = 0; i < (long)nPoints; ++i) {
+        const double plat = pointsY[i], plon = pointsX[i];
+        double px = -1., py = -1.;
+        double min_cos_d = min_grid_cos_d, min_d = acos(min_cos_d);
+        size_t lb = 0, hi = m; /* lower_bound on lat */
+        while (lb < hi) { const size_t mid = (lb + hi) / 2; if (ll[mid].lat < plat) lb = mid + 1; else hi = mid; }
+        for (size_t it = lb; it < m; ++it) { /* :1191-1208 */
+            const double dlon = ll[it].lon - plon;
+            if (fabs(ll[it].lat - plat) > min_d) break;
+            const double cos_d = cos(ll[it].lat) * cos(plat) * cos(dlon) + sin(ll[it].lat) * sin(plat);
+            if (cos_d > min_cos_d) { min_cos_d = cos_d; min_d = acos(min_cos_d); px = ll[it].x; py = ll[it].y; }
+        }
+        for (size_t it2 = lb; it2 > 0; ) { /* :1210-1228 */
+            --it2;
+            const double dlon = ll[it2].lon - plon;
+            if (fabs(ll[it2].lat - plat) > min_d) break;
+            const double cos_d = cos(ll[it2].lat) * cos(plat) * cos(dlon) + sin(ll[it2].lat) * sin(plat);
+            if (cos_d > min_cos_d) { min_cos_d = cos_d; min_d = acos(min_cos_d); px = ll[it2].x; py = ll[it2].y; }
+        }
+        pointsY[i] = py;
+        pointsX[i] = px;
+    }
+    free(ll);
+    return ORC_OK;
+}
+
+/* flannTranslatePointsToClosestInputCell, :991-1067.  nanoflann (include/nanoflann/nanoflann.hpp, vendored in the
+ * reference) returns the matches inside the squared radius sorted by distance; the first one is the cell with the smallest
+ * kdtree_distance (:966-972) -- found here by exhaustive search, which defines the same result except among exactly
+ * equidistant cells (tree order there, lowest index here). */
+int orc_flann_translate_points(double maxDist, double* pointsX, double* pointsY, size_t nPoints, const double* lonVals, const double* latVals,
+                               size_t orgX, size_t orgY)
+{
+    if (!(maxDist > 0)) return ORC_ERROR;
+    maxDist /= 6371000.; /* MIFI_EARTH_RADIUS_M */
+    const size_t n = orgX * orgY;
+    double* pts = (double*)malloc(3 * (n + 1) * sizeof(double));
+    if (!pts) return ORC_ERROR;
+    for (size_t pos = 0; pos < n; ++pos) {
+        if (!(isnan(latVals[pos]) || isnan(lonVals[pos]))) {
+            const double sinLat = sin(latVals[pos]), cosLat = cos(latVals[pos]), sinLon = sin(lonVals[pos]), cosLon = cos(lonVals[pos]);
+            pts[3 * pos] = cosLat * cosLon; pts[3 * pos + 1] = cosLat * sinLon; pts[3 * pos + 2] = sinLat;
+        } else {
+            pts[3 * pos] = pts[3 * pos + 1] = pts[3 * pos + 2] = nan("");
+        }
+    }
+    const double search_radius = maxDist * maxDist;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long i = 0; i < (long)nPoints; ++i) {
+        const double sinLat = sin(pointsY[i]), cosLat = cos(pointsY[i]), sinLon = sin(pointsX[i]), cosLon = cos(pointsX[i]);
+        const double q0 = cosLat * cosLon, q1 = cosLat * sinLon, q2 = sinLat;
+        double best = search_radius;
+        size_t bestPos = n;
+        for (size_t pos = 0; pos < n; ++pos) {
+            const double d0 = q0 - pts[3 * pos], d1 = q1 - pts[3 * pos + 1], d2 = q2 - pts[3 * pos + 2];
+            const double d = d0 * d0 + d1 * d1 + d2 * d2;
+            if (d < best) { best = d; bestPos = pos; } /* addPoint: dist < radius; NaN never */
+        }
+        if (bestPos < n) { pointsX[i] = (double)(bestPos % orgX); pointsY[i] = (double)(bestPos / orgX); }
+        else { pointsX[i] = -1000; pointsY[i] = -1000; }
+    }
+    free(pts);
+    return ORC_OK;
+}

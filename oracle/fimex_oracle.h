@@ -78,6 +78,12 @@ int orc_points2position(double* points, size_t n, const double* axis, int num, i
 size_t orc_bad2nanf(float* begin, float* end, float badVal);
 size_t orc_nanf2bad(float* begin, float* end, float badVal);
 
+/* coordinate-based nearest neighbour plans, src/CDMInterpolator.cc:991-1217 (lon / lat in rad, fields [orgY][orgX]) */
+double orc_get_grid_distance(const double* lonVals, const double* latVals, size_t orgX, size_t orgY);
+int orc_fast_translate_points(double* pointsX, double* pointsY, size_t n, const double* lonVals, const double* latVals, size_t orgX, size_t orgY);
+int orc_flann_translate_points(double maxDist, double* pointsX, double* pointsY, size_t n, const double* lonVals, const double* latVals,
+                               size_t orgX, size_t orgY);
+
 /* 1-D blends between two fields (time / vertical interpolation), src/interpolation.c:1030-1156 */
 enum { ORC_1D_NEAREST = 0, ORC_1D_LINEAR, ORC_1D_LINEAR_WEAK_EXTRAPOL, ORC_1D_LINEAR_NO_EXTRAPOL, ORC_1D_LINEAR_CONST_EXTRAPOL,
        ORC_1D_LOG, ORC_1D_LOG_LOG };

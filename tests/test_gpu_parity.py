@@ -558,3 +558,70 @@ def test_blend_device_in_place_and_double(fa):
     fa.get_values_1d_device(fa.BLEND_LINEAR, fA.data_ptr(), fB.data_ptr(), fA.data_ptr(), A.size, 2., 5., 3.)  # out aliases A
     torch.cuda.synchronize()
     assert cases.same(fA.cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------- coordinate-based nearest neighbour plans
+from test_oracle_props import _curvilinear_grid, _great_circle_cos
+
+
+def _same_cells_or_ties(gx, gy, wx, wy, metric_of, none):
+    """identical plans; where they differ, both candidates must be numerically equidistant (ties are unspecified)."""
+    diff = (gx != wx) | (gy != wy)
+    if diff.any():
+        assert not np.any((gx[diff] == none) | (wx[diff] == none))
+        mg, mw = metric_of(np.nonzero(diff)[0], gx[diff], gy[diff]), metric_of(np.nonzero(diff)[0], wx[diff], wy[diff])
+        np.testing.assert_allclose(mg, mw, rtol=0, atol=1e-15)
+    return diff.mean()
+
+
+@pytest.mark.parametrize("shape,jitter", [((60, 45), 0.3), ((200, 150), 0.3), ((64, 64), 0.0), ((1, 7), 0.2), ((5, 1), 0.2)])
+def test_coord_nearest_matches_oracle(fa, shape, jitter):
+    nx, ny = shape
+    lon, lat = _curvilinear_grid(nx, ny, seed=nx + ny, jitter=jitter, nan=min(5, nx * ny // 10))
+    rng = np.random.default_rng(nx)
+    qlon = np.radians(rng.uniform(4.0, 17.0, 20000)); qlat = np.radians(rng.uniform(57.0, 65.5, 20000))
+    qlon[:3] = [np.nan, 0.1, 0.2]; qlat[:3] = [1.0, np.nan, 3.0]
+    assert abs(fa.grid_distance_host(lon, lat) - oracle.grid_distance(lon, lat)) < 1e-12
+    gx, gy = fa.coord_nearest_host(qlon, qlat, lon, lat)
+    wx, wy = oracle.fast_translate_points(qlon, qlat, lon, lat)
+    def metric(i, x, y):
+        k = (y * nx + x).astype(int)
+        return _great_circle_cos(qlon[i], qlat[i], lon.ravel()[k], lat.ravel()[k])
+    assert _same_cells_or_ties(gx, gy, wx, wy, metric, -1) < 0.02
+    assert (gx >= 0).any() and (gx == -1).any()
+    # the plan applies as row a1
+    f = cases.field(2, ny, nx, seed=3)
+    got = fa.RegridPlan(oracle.COORD_NN, gx, gy, nx, ny, 200, 100).apply_host(f)
+    want = oracle.interpolate_values(oracle.COORD_NN, gx, gy, f, nx, ny, 200, 100)
+    assert cases.same(got, want)
+
+
+@pytest.mark.parametrize("shape,maxDist", [((60, 45), 3000.0), ((200, 150), 2500.0), ((64, 64), 4000.0), ((30, 20), 2.0e7), ((30, 20), 1.0)])
+def test_coord_kdtree_matches_oracle(fa, shape, maxDist):
+    nx, ny = shape
+    lon, lat = _curvilinear_grid(nx, ny, seed=nx * 3 + ny, jitter=0.3 if nx != 64 else 0.0, nan=5)
+    rng = np.random.default_rng(ny)
+    nq = 3000 if maxDist > 1e6 else 20000
+    qlon = np.radians(rng.uniform(4.0, 17.0, nq)); qlat = np.radians(rng.uniform(57.0, 65.5, nq))
+    gx, gy = fa.coord_kdtree_host(maxDist, qlon, qlat, lon, lat)
+    wx, wy = oracle.flann_translate_points(maxDist, qlon, qlat, lon, lat)
+    def xyz(lo, la):
+        return np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)], -1)
+    def metric(i, x, y):
+        k = (y * nx + x).astype(int)
+        return ((xyz(qlon[i], qlat[i]) - xyz(lon.ravel()[k], lat.ravel()[k])) ** 2).sum(-1)
+    assert _same_cells_or_ties(gx, gy, wx, wy, metric, -1000) < 0.02
+    if maxDist > 1e6:
+        assert (gx >= 0).all()       # everything is within 20 000 km
+    elif maxDist < 10:
+        assert (gx == -1000).all()   # nothing within a metre
+    else:
+        assert (gx >= 0).any() and (gx == -1000).any()
+
+
+def test_coord_search_rejects_bad_arguments(fa):
+    lon, lat = _curvilinear_grid(10, 8, seed=1)
+    with pytest.raises(fa.FimexAmdError):
+        fa.coord_kdtree_host(0.0, lon[0], lat[0], lon, lat)
+    with pytest.raises(fa.FimexAmdError):
+        fa.coord_nearest_host(lon[0], lat[0], np.full((8, 10), np.nan), lat)

@@ -197,3 +197,43 @@ def test_coordtest_packed_shorts_stay_shorts(tmp_path, golden_dir):
         assert np.array_equal(got, want), n
         if n == "air_temperature":
             assert (got != np.int16(bad)).mean() > 0.1 and (a[2] != np.int16(bad)).all()
+
+
+@pytest.mark.parametrize("method,code,none", [("coord_nearestneighbor", oracle.COORD_NN, -1), ("coord_kdtree", oracle.COORD_NN_KD, -1000)])
+def test_coordtest_by_its_stored_coordinates(tmp_path, golden_dir, method, code, none):
+    """changeProjectionByCoordinates (src/CDMInterpolator.cc:1335-1420): the source grid is described by coordTest.nc's 2-D
+    longitude / latitude variables, the target cells take the value of the closest source cell.  The reference's tests of
+    these methods need files that are not shipped (test/testInterpolator.cc:77-102); pinned here by the restatement."""
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "coordTest.nc"), "r", mmap=False) as f:
+        v = f.variables
+        x, y = v["x"].data.astype(np.float64), v["y"].data.astype(np.float64)
+        lon2d, lat2d = v["longitude"].data.astype(np.float64), v["latitude"].data.astype(np.float64)
+        proj = v["projection_1"].proj4.decode()
+        t = np.ascontiguousarray(v["air_temperature"].data.astype(np.int16)).reshape(4, 1, 11, 11)
+    for name, a in (("x", x), ("y", y), ("lon2d", lon2d), ("lat2d", lat2d)):
+        a.tofile(tmp_path / (name + ".f64"))
+    olon = np.linspace(-14.5, -10.0, 120); olat = np.linspace(28.8, 32.6, 100)
+    olon.tofile(tmp_path / "ox.f64"); olat.tofile(tmp_path / "oy.f64")
+    t.tofile(tmp_path / "t.i16")
+    lines = ["proj " + proj, "xaxis %s" % (tmp_path / "x.f64"), "yaxis %s" % (tmp_path / "y.f64"), "lon2d %s" % (tmp_path / "lon2d.f64"),
+             "lat2d %s" % (tmp_path / "lat2d.f64"), "method " + method, "outproj " + GEO, "outx %s degrees_east" % (tmp_path / "ox.f64"),
+             "outy %s degrees_north" % (tmp_path / "oy.f64"), "var air_temperature 1 %s -32767 type short" % (tmp_path / "t.i16"),
+             "get air_temperature 3"]
+    if method == "coord_kdtree":
+        lines.insert(5, "maxdist 40000")
+    out, stdout = _run(tmp_path, lines)
+    assert "outX 120 outY 100" in stdout and "reduced" not in stdout
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    qlon, qlat = np.meshgrid(np.radians(olon), np.radians(olat))
+    if code == oracle.COORD_NN:
+        wx, wy = oracle.fast_translate_points(qlon.ravel(), qlat.ravel(), np.radians(lon2d), np.radians(lat2d))
+    else:
+        wx, wy = oracle.flann_translate_points(40000.0, qlon.ravel(), qlat.ravel(), np.radians(lon2d), np.radians(lat2d))
+    assert ((px == wx) & (py == wy)).mean() > 0.995  # equidistant cells may be taken either way
+    assert (px >= 0).mean() > 0.3 and (px == none).any()
+    f = oracle.data2interpolation_array(t[3], -32767.0)
+    want = oracle.interpolation_array2data(oracle.interpolate_values(code, px, py, f, 11, 11, 120, 100), oracle.CDM_SHORT, -32767.0)
+    got = np.fromfile(out / "air_temperature_3.raw", dtype=np.int16).reshape(want.shape)
+    assert np.array_equal(got, want)
+    assert set(np.unique(got)) <= set(np.unique(t[3])) | {-32767}  # nearest neighbour: only values of the source

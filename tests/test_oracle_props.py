@@ -316,3 +316,56 @@ def test_typed_round_trip_of_packed_shorts():
     f = oracle.data2interpolation_array(a, -32767.0)
     assert np.isnan(f).sum() == (a == -32767).sum()
     assert np.array_equal(oracle.interpolation_array2data(f, oracle.CDM_SHORT, -32767.0), a)
+
+
+# ---------------------------------------------------------------- coordinate-based nearest neighbour plans
+def _curvilinear_grid(nx, ny, seed, jitter=0.3, nan=0):
+    """lon / lat (rad) of a rotated, slightly irregular grid, [ny][nx]."""
+    rng = np.random.default_rng(seed)
+    i, j = np.meshgrid(np.arange(nx), np.arange(ny))
+    u = (i + jitter * rng.uniform(-1, 1, i.shape)) * 0.05
+    v = (j + jitter * rng.uniform(-1, 1, i.shape)) * 0.04
+    lon = np.radians(5 + 0.9 * u - 0.3 * v)
+    lat = np.radians(58 + 0.35 * u + 0.8 * v)
+    if nan:
+        k = rng.choice(lon.size, nan, replace=False)
+        lon.reshape(-1)[k] = np.nan
+    return lon, lat
+
+
+def _great_circle_cos(lon0, lat0, lon1, lat1):
+    return np.cos(lat1) * np.cos(lat0) * np.cos(lon1 - lon0) + np.sin(lat1) * np.sin(lat0)
+
+
+def test_fast_translate_finds_the_closest_cell_within_the_region_of_influence():
+    lon, lat = _curvilinear_grid(60, 45, seed=1, nan=5)
+    rng = np.random.default_rng(2)
+    qlon = np.radians(rng.uniform(4.5, 8.5, 3000)); qlat = np.radians(rng.uniform(57.5, 61.5, 3000))
+    px, py = oracle.fast_translate_points(qlon, qlat, lon, lat)
+    roi = oracle.grid_distance(lon, lat)
+    assert 0 < roi < np.radians(0.5)
+    cosd = _great_circle_cos(qlon[:, None], qlat[:, None], lon.ravel()[None], lat.ravel()[None])
+    cosd = np.where(np.isnan(cosd), -2, cosd)
+    best = cosd.argmax(axis=1)
+    inside = cosd.max(axis=1) > np.cos(roi)
+    assert inside.any() and (~inside).any()
+    assert np.all(px[~inside] == -1) and np.all(py[~inside] == -1)
+    agree = (px[inside] == best[inside] % 60) & (py[inside] == best[inside] // 60)
+    assert agree.mean() > 0.999  # numpy's cos differs from libm's in the last bit at exact near-ties only
+
+
+def test_flann_translate_is_the_closest_cell_within_max_dist():
+    lon, lat = _curvilinear_grid(50, 40, seed=3, nan=4)
+    rng = np.random.default_rng(4)
+    qlon = np.radians(rng.uniform(4.5, 8.0, 2000)); qlat = np.radians(rng.uniform(57.5, 60.5, 2000))
+    maxDist = 4000.0
+    px, py = oracle.flann_translate_points(maxDist, qlon, qlat, lon, lat)
+    def xyz(lo, la):
+        return np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)], -1)
+    d2 = ((xyz(qlon, qlat)[:, None, :] - xyz(lon.ravel(), lat.ravel())[None]) ** 2).sum(-1)
+    d2 = np.where(np.isnan(d2), 9, d2)
+    inside = d2.min(axis=1) < (maxDist / 6371000.) ** 2
+    best = d2.argmin(axis=1)
+    assert inside.any() and (~inside).any()
+    assert np.all(px[~inside] == -1000)
+    assert ((px[inside] == best[inside] % 50) & (py[inside] == best[inside] // 50)).mean() > 0.999

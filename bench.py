@@ -30,11 +30,13 @@ def log(*a):
 
 
 def build_plan(fa, torch, wl, method, stream):
-    """Plan build on the GPU: target lon/lat -> fractional source indices -> compact plan."""
-    lon, lat = wl.target_lonlat()
+    """Plan build on the GPU: target axes -> geographic lon/lat (projection) -> fractional source indices -> compact plan."""
     ax, ay = wl.source_axes_rad()
-    d_px = torch.from_numpy(lon).cuda()
-    d_py = torch.from_numpy(lat).cuda()
+    n = wl.outX * wl.outY
+    d_px = torch.empty(n, dtype=torch.float64, device="cuda")
+    d_py = torch.empty(n, dtype=torch.float64, device="cuda")
+    rlon, rlat = wl.target_axes_deg()
+    fa.project_axes_device(wl.target_proj, wl.source_proj, np.radians(rlon), np.radians(rlat), d_px.data_ptr(), d_py.data_ptr(), stream)
     fa.points2position_device(d_px.data_ptr(), d_px.numel(), ax, fa.LONGITUDE, stream)
     fa.points2position_device(d_py.data_ptr(), d_py.numel(), ay, fa.LATITUDE, stream)
     plan = fa.RegridPlan.from_device(method, d_px.data_ptr(), d_py.data_ptr(), d_px.numel(),

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <mutex>
+#include <set>
 #include <string>
 #include <utility>
 
@@ -123,5 +125,19 @@ constexpr int kXcds = 8;     // MI355X accelerator complex dies, one L2 each
 constexpr int kBlock = 256;  // 4 waves, one per SIMD
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per device and kernel
+// (a process may drive several devices through fimex_amd_set_device; the calls are re-entrant)
+inline void allow_dynamic_lds(const void* kernel, size_t bytes)
+{
+    static std::mutex mtx;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    FA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mtx);
+    if (done.count({dev, kernel})) return;
+    FA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.insert({dev, kernel});
+}
 
 }  // namespace fimex_amd

@@ -1302,12 +1302,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         a.sumAlgo = tuning("SUM_ALGO", 1);
         constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandW * sizeof(float) +
                                     (size_t)kV2Waves * 4 * sizeof(unsigned int);
-        static bool attrSet = false;
-        if (!attrSet) {
-            FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fill2d_kernel_v2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)ldsBytes));
-            attrSet = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void*>(&fill2d_kernel_v2), ldsBytes);
         fill2d_kernel_v2<<<dim3((uint32_t)nz), kV2Threads, ldsBytes, stream>>>(a);
         FA_HIP(hipGetLastError());
         collect_stats(stats, nz, h_nChanged, stream, "fill2d");
@@ -1362,12 +1357,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         a.sumAlgo = tuning("SUM_ALGO", 1);
         constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandWC * (sizeof(float) + 1) +
                                     (size_t)kV2Waves * 4 * sizeof(unsigned int);
-        static bool attrSet = false;
-        if (!attrSet) {
-            FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&creepfill_kernel_v2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)ldsBytes));
-            attrSet = true;
-        }
+        allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
         creepfill_kernel_v2<<<dim3((uint32_t)nz), kV2Threads, ldsBytes, stream>>>(a);
         FA_HIP(hipGetLastError());
         collect_stats(stats, nz, h_nChanged, stream, what);

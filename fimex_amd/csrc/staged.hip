@@ -410,12 +410,7 @@ template <int STENCIL, int PER, int KMAX>
 void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
     constexpr size_t ldsBytes = 2 * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
-    static bool attrSet = false;
-    if (!attrSet) {
-        FA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-        attrSet = true;
-    }
+    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX>), ldsBytes);
     staged_apply<STENCIL, PER, KMAX><<<grid, kBlock, ldsBytes, stream>>>(a);
 }
 

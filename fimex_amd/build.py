@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libfimex_amd.so")
 HOSTLIB = os.path.join(HERE, "libfimex_amd_host.so")
 HOSTCLI = os.path.join(HERE, "host_cli.so")  # an executable; the .so suffix keeps it out of git and lets it travel to the GPU box
 
-DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip", "projection.hip", "coordsearch.hip"]
+DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip", "projection.hip", "coordsearch.hip", "hostpipe.hip"]
 
 # -ffp-contract=off: the kernels reproduce the reference's IEEE arithmetic operation by operation
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

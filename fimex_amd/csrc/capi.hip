@@ -215,6 +215,12 @@ int fimex_amd_regrid_apply_host(const fimex_amd_regrid_plan* plan, const float* 
         FA_REQUIRE(outCapacity >= *newSize, "output buffer too small");
         if (nz == 0) return;
         ScopedDevice dev(plan->device);
+        // slices are independent: stream them through pinned staging, transfers overlapping the kernels
+        if (pipelined_slices(plan->device, inData, inLayer * sizeof(float), outData, outLayer * sizeof(float), 0, 0, nz,
+                             [&](const void* dIn, void* dOut, float*, float*, size_t nzc, hipStream_t st) {
+                                 apply_device(*plan, static_cast<const float*>(dIn), nzc, static_cast<float*>(dOut), st);
+                             }))
+            return;
         ScopedStream stream;
         DeviceArray<float> d_in(nz * inLayer), d_out(nz * outLayer);
         FA_HIP(hipMemcpyAsync(d_in.get(), inData, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
@@ -446,6 +452,28 @@ void regrid_slice(const fimex_amd_regrid_plan* plan, bool typed, const void* inD
                            "vector reprojection does not match the regrid plan");
     const size_t elemOther = (vector && typed) ? cdm_type_size(counterpartType) : sizeof(float);
     ScopedDevice dev(plan->device);
+    if (!vector && nPre == 0 && nPost == 0) {
+        // conversion, regrid, conversion per chunk of slices, transfers streamed
+        const bool convert = typed && dataType != FIMEX_AMD_CDM_FLOAT;
+        if (pipelined_slices(plan->device, inData, inLayer * elem, outData, outLayer * elem, convert ? inLayer : 0, typed ? outLayer : 0, nz,
+                             [&](const void* dIn, void* dOut, float* fIn, float* fOut, size_t nzc, hipStream_t st) {
+                                 const float* src = static_cast<const float*>(dIn);
+                                 if (convert) {
+                                     launch_data2interpolation(dIn, dataType, nzc * inLayer, badValue, fIn, st);
+                                     src = fIn;
+                                 } else {
+                                     launch_bad2nan(const_cast<float*>(src), nzc * inLayer, (float)badValue, st);  // staging copy, not the caller's
+                                 }
+                                 if (typed) {
+                                     apply_device(*plan, src, nzc, fOut, st);
+                                     launch_interpolation2data(fOut, nzc * outLayer, dataType, badValue, dOut, st);
+                                 } else {
+                                     apply_device(*plan, src, nzc, static_cast<float*>(dOut), st);
+                                     launch_nan2bad(static_cast<float*>(dOut), nzc * outLayer, (float)badValue, st);
+                                 }
+                             }))
+            return;
+    }
     ScopedStream stream;
     hipStream_t st = stream.get();
     auto run = [&](const fimex_amd_process2d* list, size_t n, float* d, size_t nx, size_t ny) {

@@ -1,0 +1,213 @@
+// The *_host entry points move caller-owned, pageable buffers over PCIe: that, not the kernels, is what a drop-in caller
+// waits for (measured on this pool, scripts/calib/pcie.hip: pageable hipMemcpy 24 GB/s up / 32 GB/s down, pinned 57 GB/s
+// each way and 75 GB/s duplex, hipHostRegister 50 ms per GB -- not worth it per call, host memcpy 30 GB/s on one thread,
+// 127 GB/s on eight).  So slices are streamed: a few worker threads copy the next chunk into pinned staging while the DMA
+// engines upload the previous one, the kernels run, and results flow back the same way in the other direction.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace fimex_amd {
+
+namespace {
+
+constexpr size_t kPinBytes = (size_t)64 << 20;   // pinned staging per slot and direction
+constexpr size_t kDevFloatBytes = (size_t)128 << 20;  // float scratch per slot and direction (typed slices)
+constexpr int kSlots = 3;
+constexpr int kMaxCached = 4;
+
+// memcpy on several threads: the workers live as long as the pipe
+class ParallelCopier {
+public:
+    explicit ParallelCopier(int workers)
+    {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { run(i); });
+    }
+    ~ParallelCopier()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; ++generation_; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void copy(void* dst, const void* src, size_t bytes)
+    {
+        const size_t parts = threads_.size() + 1;
+        if (bytes < ((size_t)1 << 20) || threads_.empty()) { std::memcpy(dst, src, bytes); return; }
+        const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            dst_ = static_cast<char*>(dst);
+            src_ = static_cast<const char*>(src);
+            bytes_ = bytes;
+            per_ = per;
+            pending_ = (int)threads_.size();
+            ++generation_;
+        }
+        cv_.notify_all();
+        part(threads_.size());  // the caller takes the last part
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
+
+private:
+    void part(size_t k)
+    {
+        const size_t off = k * per_;
+        if (off < bytes_) std::memcpy(dst_ + off, src_ + off, std::min(per_, bytes_ - off));
+    }
+    void run(int k)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+            }
+            part((size_t)k);
+            std::lock_guard<std::mutex> l(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t bytes_ = 0, per_ = 0;
+    int pending_ = 0;
+};
+
+struct Slot {
+    char *pinIn = nullptr, *pinOut = nullptr, *dRawIn = nullptr, *dRawOut = nullptr;
+    float *dFIn = nullptr, *dFOut = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+class HostPipe {
+public:
+    explicit HostPipe(int device) : device(device), copier(worker_count())
+    {
+        for (Slot& s : slots) {
+            FA_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pinIn), kPinBytes));
+            FA_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pinOut), kPinBytes));
+            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dRawIn), kPinBytes));
+            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dRawOut), kPinBytes));
+            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFIn), kDevFloatBytes));
+            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFOut), kDevFloatBytes));
+            FA_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            FA_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+    }
+    ~HostPipe()
+    {
+        for (Slot& s : slots) {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            if (s.pinIn) (void)hipHostFree(s.pinIn);
+            if (s.pinOut) (void)hipHostFree(s.pinOut);
+            if (s.dRawIn) (void)hipFree(s.dRawIn);
+            if (s.dRawOut) (void)hipFree(s.dRawOut);
+            if (s.dFIn) (void)hipFree(s.dFIn);
+            if (s.dFOut) (void)hipFree(s.dFOut);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+        }
+    }
+    static int worker_count()
+    {
+        const int forced = tuning("HOST_COPY_THREADS", 0);
+        if (forced > 0) return forced - 1;
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::min(7u, std::max(1u, hw / 4));
+    }
+    int device;
+    Slot slots[kSlots];
+    ParallelCopier copier;
+};
+
+std::mutex g_poolMutex;
+std::vector<HostPipe*> g_pool;
+
+HostPipe* acquire_pipe(int device)
+{
+    {
+        std::lock_guard<std::mutex> l(g_poolMutex);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i]->device == device) {
+                HostPipe* p = g_pool[i];
+                g_pool.erase(g_pool.begin() + (long)i);
+                return p;
+            }
+    }
+    return new HostPipe(device);  // concurrent callers (interpolateValues is re-entrant) each get their own
+}
+
+void release_pipe(HostPipe* p)
+{
+    {
+        std::lock_guard<std::mutex> l(g_poolMutex);
+        if ((int)g_pool.size() < kMaxCached) { g_pool.push_back(p); return; }
+    }
+    delete p;
+}
+
+struct PipeLease {
+    explicit PipeLease(int device) : pipe(acquire_pipe(device)) {}
+    ~PipeLease() { release_pipe(pipe); }
+    HostPipe* pipe;
+};
+
+}  // namespace
+
+// in / out: nz slices of inSliceBytes / outSliceBytes in caller memory.  fn(dRawIn, dRawOut, dFIn, dFOut, nzc, stream) turns
+// nzc uploaded slices into nzc result slices in dRawOut (dFIn / dFOut: float scratch of inSliceFloats / outSliceFloats per
+// slice).  Returns false when a single slice does not fit the staging buffers (the caller takes the plain path).
+bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out, size_t outSliceBytes, size_t inSliceFloats,
+                      size_t outSliceFloats, size_t nz, const SliceChunkFn& fn)
+{
+    if (tuning("HOST_PIPE", 1) == 0 || nz == 0) return false;
+    size_t nzc = std::min({kPinBytes / std::max<size_t>(inSliceBytes, 1), kPinBytes / std::max<size_t>(outSliceBytes, 1),
+                           kDevFloatBytes / std::max<size_t>(inSliceFloats * 4, 1), kDevFloatBytes / std::max<size_t>(outSliceFloats * 4, 1)});
+    if (nzc == 0) return false;
+    nzc = std::min(nzc, nz);
+    PipeLease lease(device);
+    HostPipe& p = *lease.pipe;
+    const size_t nChunks = (nz + nzc - 1) / nzc;
+    const char* src = static_cast<const char*>(in);
+    char* dst = static_cast<char*>(out);
+    auto count = [&](size_t c) { return std::min(nzc, nz - c * nzc); };
+    auto finish = [&](size_t c) {
+        Slot& s = p.slots[c % kSlots];
+        FA_HIP(hipEventSynchronize(s.done));
+        p.copier.copy(dst + c * nzc * outSliceBytes, s.pinOut, count(c) * outSliceBytes);
+    };
+    size_t finished = 0;
+    try {
+        for (size_t c = 0; c < nChunks; ++c) {
+            Slot& s = p.slots[c % kSlots];
+            if (c >= (size_t)kSlots) { finish(c - kSlots); finished = c - kSlots + 1; }
+            const size_t k = count(c);
+            p.copier.copy(s.pinIn, src + c * nzc * inSliceBytes, k * inSliceBytes);
+            FA_HIP(hipMemcpyAsync(s.dRawIn, s.pinIn, k * inSliceBytes, hipMemcpyHostToDevice, s.stream));
+            fn(s.dRawIn, s.dRawOut, s.dFIn, s.dFOut, k, s.stream);
+            FA_HIP(hipMemcpyAsync(s.pinOut, s.dRawOut, k * outSliceBytes, hipMemcpyDeviceToHost, s.stream));
+            FA_HIP(hipEventRecord(s.done, s.stream));
+        }
+        for (size_t c = finished; c < nChunks; ++c) finish(c);
+    } catch (...) {
+        for (Slot& s : p.slots) (void)hipStreamSynchronize(s.stream);  // nothing of this call may still be in flight
+        throw;
+    }
+    return true;
+}
+
+}  // namespace fimex_amd

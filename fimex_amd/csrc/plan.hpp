@@ -20,6 +20,8 @@
 
 #include "common.hpp"
 
+#include <functional>
+
 namespace fimex_amd {
 
 constexpr uint32_t kInvalidPos = 0xFFFFFFFFu;
@@ -129,6 +131,11 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
 
 void run_scan_sum(const float* d_values, size_t n, int mode, double average, int algo, double* h_sum, size_t* h_nUndefined,
                   hipStream_t stream);
+
+// hostpipe.hip: streamed transfers for the *_host entry points
+using SliceChunkFn = std::function<void(const void* dRawIn, void* dRawOut, float* dFIn, float* dFOut, size_t nzc, hipStream_t stream)>;
+bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out, size_t outSliceBytes, size_t inSliceFloats,
+                      size_t outSliceFloats, size_t nz, const SliceChunkFn& fn);
 
 // tuning knobs read once from the environment (FIMEX_AMD_<NAME>), for bench sweeps
 int tuning(const char* name, int fallback);

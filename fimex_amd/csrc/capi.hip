@@ -127,9 +127,9 @@ template <typename F>
 void with_device_copy(float* h, size_t n, hipStream_t stream, F&& body)
 {
     DeviceArray<float> d(n);
-    FA_HIP(hipMemcpyAsync(d.get(), h, n * sizeof(float), hipMemcpyHostToDevice, stream));
+    host_to_device(d.get(), h, n * sizeof(float), stream);
     body(d.get());
-    FA_HIP(hipMemcpyAsync(h, d.get(), n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    device_to_host(h, d.get(), n * sizeof(float), stream);
     FA_HIP(hipStreamSynchronize(stream));
 }
 
@@ -164,8 +164,8 @@ int fimex_amd_regrid_plan_create(int funcType, const double* px, const double* p
         auto plan = new_plan(funcType, nPoints, inX, inY, outX, outY);
         ScopedStream stream;
         DeviceArray<double> d_px(nPoints), d_py(nPoints);
-        FA_HIP(hipMemcpyAsync(d_px.get(), px, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
-        FA_HIP(hipMemcpyAsync(d_py.get(), py, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_px.get(), px, nPoints * sizeof(double), stream.get());
+        host_to_device(d_py.get(), py, nPoints * sizeof(double), stream.get());
         build_plan(*plan, d_px.get(), d_py.get(), stream.get());
         stream.sync();
         *out = plan.release();
@@ -223,9 +223,9 @@ int fimex_amd_regrid_apply_host(const fimex_amd_regrid_plan* plan, const float* 
             return;
         ScopedStream stream;
         DeviceArray<float> d_in(nz * inLayer), d_out(nz * outLayer);
-        FA_HIP(hipMemcpyAsync(d_in.get(), inData, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_in.get(), inData, d_in.bytes(), stream.get());
         apply_device(*plan, d_in.get(), nz, d_out.get(), stream.get());
-        FA_HIP(hipMemcpyAsync(outData, d_out.get(), d_out.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(outData, d_out.get(), d_out.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -277,11 +277,11 @@ int fimex_amd_vector_reproject_values_host(const fimex_amd_vector_plan* plan, fl
         ScopedStream stream;
         const size_t n = oz * layer;
         DeviceArray<float> d_u(n), d_v(n);
-        FA_HIP(hipMemcpyAsync(d_u.get(), u, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
-        FA_HIP(hipMemcpyAsync(d_v.get(), v, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_u.get(), u, n * sizeof(float), stream.get());
+        host_to_device(d_v.get(), v, n * sizeof(float), stream.get());
         launch_vector_values(*plan, d_u.get(), d_v.get(), oz, stream.get());
-        FA_HIP(hipMemcpyAsync(u, d_u.get(), n * sizeof(float), hipMemcpyDeviceToHost, stream.get()));
-        FA_HIP(hipMemcpyAsync(v, d_v.get(), n * sizeof(float), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(u, d_u.get(), n * sizeof(float), stream.get());
+        device_to_host(v, d_v.get(), n * sizeof(float), stream.get());
         stream.sync();
     });
 }
@@ -493,10 +493,10 @@ void regrid_slice(const fimex_amd_regrid_plan* plan, bool typed, const void* inD
         DeviceArray<unsigned char> d_raw;
         if (typed && type != FIMEX_AMD_CDM_FLOAT) {
             d_raw.allocate(nz * inLayer * bytesPerElem);
-            FA_HIP(hipMemcpyAsync(d_raw.get(), h_in, d_raw.bytes(), hipMemcpyHostToDevice, st));
+            host_to_device(d_raw.get(), h_in, d_raw.bytes(), st);
             launch_data2interpolation(d_raw.get(), type, d_in.size(), bad, d_in.get(), st);
         } else {
-            FA_HIP(hipMemcpyAsync(d_in.get(), h_in, d_in.bytes(), hipMemcpyHostToDevice, st));
+            host_to_device(d_in.get(), h_in, d_in.bytes(), st);
             launch_bad2nan(d_in.get(), d_in.size(), (float)bad, st);
         }
         run(pre, nPre, d_in.get(), plan->inX, plan->inY);
@@ -515,11 +515,11 @@ void regrid_slice(const fimex_amd_regrid_plan* plan, bool typed, const void* inD
     if (typed) {
         DeviceArray<unsigned char> d_typed(d_main.size() * elem);
         launch_interpolation2data(d_main.get(), d_main.size(), dataType, badValue, d_typed.get(), st);
-        FA_HIP(hipMemcpyAsync(outData, d_typed.get(), d_typed.bytes(), hipMemcpyDeviceToHost, st));
+        device_to_host(outData, d_typed.get(), d_typed.bytes(), st);
         stream.sync();
     } else {
         launch_nan2bad(d_main.get(), d_main.size(), (float)badValue, st);
-        FA_HIP(hipMemcpyAsync(outData, d_main.get(), d_main.bytes(), hipMemcpyDeviceToHost, st));
+        device_to_host(outData, d_main.get(), d_main.bytes(), st);
         stream.sync();
     }
 }
@@ -571,9 +571,9 @@ int fimex_amd_data2interpolation_host(const void* in, int cdmType, size_t n, dou
         ScopedStream stream;
         DeviceArray<unsigned char> d_in(n * elem);
         DeviceArray<float> d_out(n);
-        FA_HIP(hipMemcpyAsync(d_in.get(), in, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_in.get(), in, d_in.bytes(), stream.get());
         launch_data2interpolation(d_in.get(), cdmType, n, badValue, d_out.get(), stream.get());
-        FA_HIP(hipMemcpyAsync(out, d_out.get(), d_out.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(out, d_out.get(), d_out.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -588,9 +588,9 @@ int fimex_amd_interpolation2data_host(const float* in, size_t n, int cdmType, do
         ScopedStream stream;
         DeviceArray<float> d_in(n);
         DeviceArray<unsigned char> d_out(n * elem);
-        FA_HIP(hipMemcpyAsync(d_in.get(), in, d_in.bytes(), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_in.get(), in, d_in.bytes(), stream.get());
         launch_interpolation2data(d_in.get(), n, cdmType, badValue, d_out.get(), stream.get());
-        FA_HIP(hipMemcpyAsync(out, d_out.get(), d_out.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(out, d_out.get(), d_out.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -614,9 +614,9 @@ int fimex_amd_points2position_host(double* points, size_t n, const double* axis,
         (void)current_device_checked();
         ScopedStream stream;
         DeviceArray<double> d(n);
-        FA_HIP(hipMemcpyAsync(d.get(), points, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d.get(), points, n * sizeof(double), stream.get());
         launch_points2position(d.get(), n, axis, num, axis_type, stream.get());
-        FA_HIP(hipMemcpyAsync(points, d.get(), n * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(points, d.get(), n * sizeof(double), stream.get());
         stream.sync();
     });
 }
@@ -639,12 +639,12 @@ int fimex_amd_get_values_1d_f_host(int kind, const float* A, const float* B, flo
         ScopedStream stream;
         DeviceArray<float> d(3 * n);
         if (n) {
-            FA_HIP(hipMemcpyAsync(d.get(), A, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
-            FA_HIP(hipMemcpyAsync(d.get() + n, B, n * sizeof(float), hipMemcpyHostToDevice, stream.get()));
+            host_to_device(d.get(), A, n * sizeof(float), stream.get());
+            host_to_device(d.get() + n, B, n * sizeof(float), stream.get());
         }
         if (!launch_get_values_1d_f(kind, d.get(), d.get() + n, d.get() + 2 * n, n, a, b, x, stream.get()))
             throw Error("log blend needs positive coordinates (src/interpolation.c:1137, 1149)");
-        if (n) FA_HIP(hipMemcpyAsync(out, d.get() + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, stream.get()));
+        if (n) device_to_host(out, d.get() + 2 * n, n * sizeof(float), stream.get());
         stream.sync();
     });
 }
@@ -675,13 +675,13 @@ int fimex_amd_project_values_host(const char* proj_input, const char* proj_outpu
         ScopedStream stream;
         DeviceArray<double> d(2 * num);
         if (num) {
-            FA_HIP(hipMemcpyAsync(d.get(), x, num * sizeof(double), hipMemcpyHostToDevice, stream.get()));
-            FA_HIP(hipMemcpyAsync(d.get() + num, y, num * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+            host_to_device(d.get(), x, num * sizeof(double), stream.get());
+            host_to_device(d.get() + num, y, num * sizeof(double), stream.get());
         }
         launch_project_values(proj_input, proj_output, d.get(), d.get() + num, num, stream.get());
         if (num) {
-            FA_HIP(hipMemcpyAsync(x, d.get(), num * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
-            FA_HIP(hipMemcpyAsync(y, d.get() + num, num * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+            device_to_host(x, d.get(), num * sizeof(double), stream.get());
+            device_to_host(y, d.get() + num, num * sizeof(double), stream.get());
         }
         stream.sync();
     });
@@ -708,8 +708,8 @@ int fimex_amd_project_axes_host(const char* proj_input, const char* proj_output,
         DeviceArray<double> d(2 * n);
         launch_project_axes(proj_input, proj_output, in_x_axis, in_y_axis, ix, iy, d.get(), d.get() + n, stream.get());
         if (n) {
-            FA_HIP(hipMemcpyAsync(outX, d.get(), n * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
-            FA_HIP(hipMemcpyAsync(outY, d.get() + n, n * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+            device_to_host(outX, d.get(), n * sizeof(double), stream.get());
+            device_to_host(outY, d.get() + n, n * sizeof(double), stream.get());
         }
         stream.sync();
     });
@@ -736,7 +736,7 @@ int fimex_amd_get_vector_reproject_matrix_host(const char* proj_input, const cha
         ScopedStream stream;
         DeviceArray<double> d(4 * n);
         launch_vector_reproject_matrix(proj_input, proj_output, out_x_axis, out_y_axis, xType, yType, ox, oy, d.get(), stream.get());
-        if (n) FA_HIP(hipMemcpyAsync(matrix, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        if (n) device_to_host(matrix, d.get(), d.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -751,7 +751,7 @@ int fimex_amd_get_vector_reproject_matrix_field_host(const char* proj_input, con
         ScopedStream stream;
         DeviceArray<double> d(4 * n);
         launch_vector_reproject_matrix_field(proj_input, proj_output, in_x_field, in_y_field, ox, oy, d.get(), stream.get());
-        if (n) FA_HIP(hipMemcpyAsync(matrix, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        if (n) device_to_host(matrix, d.get(), d.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -765,7 +765,7 @@ int fimex_amd_get_vector_reproject_matrix_points_host(const char* proj_input, co
         ScopedStream stream;
         DeviceArray<double> d(4 * on);
         launch_vector_reproject_matrix_points(proj_input, proj_output, inputIsMetric, out_x_points, out_y_points, on, d.get(), stream.get());
-        if (on) FA_HIP(hipMemcpyAsync(matrix, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        if (on) device_to_host(matrix, d.get(), d.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -790,9 +790,9 @@ int fimex_amd_vector_reproject_direction_scaled_host(const fimex_amd_vector_plan
         ScopedDevice dev(plan->device);
         ScopedStream stream;
         DeviceArray<float> d(oz * layer);
-        FA_HIP(hipMemcpyAsync(d.get(), angles, d.bytes(), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d.get(), angles, d.bytes(), stream.get());
         launch_vector_direction_scaled(*plan, d.get(), oz, scale, offset, stream.get());
-        FA_HIP(hipMemcpyAsync(angles, d.get(), d.bytes(), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(angles, d.get(), d.bytes(), stream.get());
         stream.sync();
     });
 }
@@ -811,13 +811,13 @@ int fimex_amd_rotate_vector_typed_host(const fimex_amd_vector_plan* plan, const 
         hipStream_t st = stream.get();
         DeviceArray<unsigned char> rawX(size * ex), rawY(size * ey), rawOut(size * eo);
         DeviceArray<float> u(size), v(size);
-        FA_HIP(hipMemcpyAsync(rawX.get(), xData, rawX.bytes(), hipMemcpyHostToDevice, st));
-        FA_HIP(hipMemcpyAsync(rawY.get(), yData, rawY.bytes(), hipMemcpyHostToDevice, st));
+        host_to_device(rawX.get(), xData, rawX.bytes(), st);
+        host_to_device(rawY.get(), yData, rawY.bytes(), st);
         launch_data2interpolation(rawX.get(), xType, size, xFill, u.get(), st);   // CDMProcessor.cc:607-608
         launch_data2interpolation(rawY.get(), yType, size, yFill, v.get(), st);
         launch_vector_values(*plan, u.get(), v.get(), oz, st);                      // :612 (whole slices only, as the reference)
         launch_interpolation2data(returnX ? u.get() : v.get(), size, outType, outFill, rawOut.get(), st);  // :614-618
-        FA_HIP(hipMemcpyAsync(outData, rawOut.get(), rawOut.bytes(), hipMemcpyDeviceToHost, st));
+        device_to_host(outData, rawOut.get(), rawOut.bytes(), st);
         stream.sync();
     });
 }
@@ -842,17 +842,17 @@ void coord_search_host(double* px, double* py, size_t nPoints, const double* lon
     ScopedStream stream;
     DeviceArray<double> d_q(2 * nPoints), d_src(2 * n);
     if (nPoints) {
-        FA_HIP(hipMemcpyAsync(d_q.get(), px, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
-        FA_HIP(hipMemcpyAsync(d_q.get() + nPoints, py, nPoints * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_q.get(), px, nPoints * sizeof(double), stream.get());
+        host_to_device(d_q.get() + nPoints, py, nPoints * sizeof(double), stream.get());
     }
     if (n) {
-        FA_HIP(hipMemcpyAsync(d_src.get(), lon, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
-        FA_HIP(hipMemcpyAsync(d_src.get() + n, lat, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d_src.get(), lon, n * sizeof(double), stream.get());
+        host_to_device(d_src.get() + n, lat, n * sizeof(double), stream.get());
     }
     run(d_q.get(), d_q.get() + nPoints, d_src.get(), d_src.get() + n, stream.get());
     if (nPoints) {
-        FA_HIP(hipMemcpyAsync(px, d_q.get(), nPoints * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
-        FA_HIP(hipMemcpyAsync(py, d_q.get() + nPoints, nPoints * sizeof(double), hipMemcpyDeviceToHost, stream.get()));
+        device_to_host(px, d_q.get(), nPoints * sizeof(double), stream.get());
+        device_to_host(py, d_q.get() + nPoints, nPoints * sizeof(double), stream.get());
     }
     stream.sync();
 }
@@ -906,8 +906,8 @@ int fimex_amd_grid_distance_host(const double* lon, const double* lat, size_t or
         (void)current_device_checked();
         ScopedStream stream;
         DeviceArray<double> d(2 * n);
-        FA_HIP(hipMemcpyAsync(d.get(), lon, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
-        FA_HIP(hipMemcpyAsync(d.get() + n, lat, n * sizeof(double), hipMemcpyHostToDevice, stream.get()));
+        host_to_device(d.get(), lon, n * sizeof(double), stream.get());
+        host_to_device(d.get() + n, lat, n * sizeof(double), stream.get());
         *maxGridDistance = grid_distance(d.get(), d.get() + n, orgX, orgY, stream.get());
     });
 }

@@ -137,6 +137,9 @@ using SliceChunkFn = std::function<void(const void* dRawIn, void* dRawOut, float
 bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out, size_t outSliceBytes, size_t inSliceFloats,
                       size_t outSliceFloats, size_t nz, const SliceChunkFn& fn);
 
+void host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t stream);
+void device_to_host(void* h_dst, const void* d_src, size_t bytes, hipStream_t stream);
+
 // tuning knobs read once from the environment (FIMEX_AMD_<NAME>), for bench sweeps
 int tuning(const char* name, int fallback);
 

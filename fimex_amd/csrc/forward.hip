@@ -14,7 +14,11 @@
 //    index reads), a ballot drops undefined values, and the reduction is finished across the wave
 //    (shuffle reduction for max / min, ordered lane scan for sum / mean so that the reference's
 //    left-to-right float additions are kept).
+#include <cstring>  // before rocprim: its texture iterator calls memset
+
 #include "plan.hpp"
+
+#include <rocprim/rocprim.hpp>
 
 #include <vector>
 
@@ -227,6 +231,45 @@ void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, hipStream_t stream)
     }
 }
 
+__global__ void __launch_bounds__(kBlock) iota_kernel(uint32_t* __restrict__ idx, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) idx[i] = i;
+}
+
+// offsets[t] = first position in the sorted keys that is >= t (t = 0 .. nOut): lower bound by binary search
+__global__ void __launch_bounds__(kBlock) csr_offsets_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t nOut, uint32_t* __restrict__ offsets)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t > nOut) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] < t) lo = mid + 1;
+        else hi = mid;
+    }
+    offsets[t] = lo;
+}
+
+__global__ void __launch_bounds__(kBlock) csr_stats_kernel(const uint32_t* __restrict__ offsets, uint32_t nOut, unsigned long long* __restrict__ stats)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t len = 0;
+    bool empty = false;
+    if (t < nOut) {
+        len = offsets[t + 1] - offsets[t];
+        empty = len == 0;
+        if (t == nOut - 1) stats[0] = offsets[nOut];  // mapped source cells
+    }
+    const unsigned long long e = __popcll(__ballot(empty));
+    uint32_t m = len;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (e) atomicAdd(&stats[2], e);
+        if (m) atomicMax(&stats[1], (unsigned long long)m);
+    }
+}
+
 }  // namespace
 
 void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
@@ -238,32 +281,30 @@ void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     forward_targets<<<dim3((uint32_t)ceil_div(nIn, kBlock)), kBlock, 0, stream>>>(
         d_px, d_py, (uint32_t)nIn, (int64_t)plan.outX, (int64_t)plan.outY, d_tgt.get());
     FA_HIP(hipGetLastError());
-    std::vector<uint32_t> tgt(nIn);
-    FA_HIP(hipMemcpyAsync(tgt.data(), d_tgt.get(), nIn * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    FA_HIP(hipStreamSynchronize(stream));
-
-    // stable counting sort by target: buckets keep source scan order (= the reference's push_back order)
-    std::vector<uint32_t> offsets(nOut + 1, 0);
-    size_t mapped = 0;
-    for (size_t i = 0; i < nIn; ++i)
-        if (tgt[i] != kInvalidPos) { offsets[tgt[i] + 1]++; mapped++; }
-    size_t maxBucket = 0, empty = 0;
-    for (size_t t = 0; t < nOut; ++t) {
-        if (offsets[t + 1] > maxBucket) maxBucket = offsets[t + 1];
-        if (offsets[t + 1] == 0) empty++;
-        offsets[t + 1] += offsets[t];
-    }
-    std::vector<uint32_t> src(mapped ? mapped : 1);
-    {
-        std::vector<uint32_t> cursor(offsets.begin(), offsets.end() - 1);
-        for (size_t i = 0; i < nIn; ++i)
-            if (tgt[i] != kInvalidPos) src[cursor[tgt[i]]++] = (uint32_t)i;
-    }
+    // CSR by a stable radix sort of (target, source index): buckets keep the source scan order, which is the
+    // reference's push_back order (src/CachedForwardInterpolation.cc:103-112); unmapped cells (key ~0) sort to the end
+    DeviceArray<uint32_t> d_idx(nIn), d_keysSorted(nIn), d_idxSorted(nIn);
+    iota_kernel<<<dim3((uint32_t)ceil_div(nIn, kBlock)), kBlock, 0, stream>>>(d_idx.get(), (uint32_t)nIn);
+    FA_HIP(hipGetLastError());
+    size_t tmpBytes = 0;
+    FA_HIP(rocprim::radix_sort_pairs(nullptr, tmpBytes, d_tgt.get(), d_keysSorted.get(), d_idx.get(), d_idxSorted.get(), nIn, 0, 32, stream));
+    DeviceArray<unsigned char> tmp(tmpBytes ? tmpBytes : 1);
+    FA_HIP(rocprim::radix_sort_pairs(tmp.get(), tmpBytes, d_tgt.get(), d_keysSorted.get(), d_idx.get(), d_idxSorted.get(), nIn, 0, 32, stream));
     plan.offsets.allocate(nOut + 1);
-    plan.src.allocate(src.size());
-    FA_HIP(hipMemcpyAsync(plan.offsets.get(), offsets.data(), (nOut + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    FA_HIP(hipMemcpyAsync(plan.src.get(), src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    DeviceArray<unsigned long long> d_stats(3);  // mapped, maxBucket, empty
+    FA_HIP(hipMemsetAsync(d_stats.get(), 0, 3 * sizeof(unsigned long long), stream));
+    csr_offsets_kernel<<<dim3((uint32_t)ceil_div(nOut + 1, kBlock)), kBlock, 0, stream>>>(d_keysSorted.get(), (uint32_t)nIn, (uint32_t)nOut,
+                                                                                          plan.offsets.get());
+    FA_HIP(hipGetLastError());
+    csr_stats_kernel<<<dim3((uint32_t)ceil_div(nOut, kBlock)), kBlock, 0, stream>>>(plan.offsets.get(), (uint32_t)nOut, d_stats.get());
+    FA_HIP(hipGetLastError());
+    unsigned long long h_stats[3] = {0, 0, 0};
+    FA_HIP(hipMemcpyAsync(h_stats, d_stats.get(), sizeof(h_stats), hipMemcpyDeviceToHost, stream));
     FA_HIP(hipStreamSynchronize(stream));
+    const size_t mapped = (size_t)h_stats[0], maxBucket = (size_t)h_stats[1], empty = (size_t)h_stats[2];
+    plan.src.allocate(mapped ? mapped : 1);
+    if (mapped) FA_HIP(hipMemcpyAsync(plan.src.get(), d_idxSorted.get(), mapped * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    FA_HIP(hipStreamSynchronize(stream));  // temporaries are released on return
     plan.info.planBytes = (nOut + 1) * sizeof(uint32_t) + mapped * sizeof(uint32_t);
     plan.info.undefinedCells = empty;
     plan.info.maxBucket = maxBucket;

@@ -17,20 +17,20 @@ constexpr double kPi = 3.1415926535897932384626433832795;  // MIFI_PI, include/f
 __device__ __forceinline__ float undefined_f() { return __uint_as_float(0x7fc00000u); }
 
 template <bool TO_NAN>
-__device__ __forceinline__ float4 replace4(float4 v, float bad)
+__device__ __forceinline__ bool hit(float v, float bad) { return TO_NAN ? (v == bad) : isnan(v); }  // :1778 / :1788
+
+// replaces in place; returns whether anything changed (unchanged groups are not written back: fill values are rare, so
+// the pass is mostly a read)
+template <bool TO_NAN>
+__device__ __forceinline__ bool replace4(float4& v, float bad)
 {
-    if (TO_NAN) {
-        v.x = (v.x == bad) ? undefined_f() : v.x;  // :1778
-        v.y = (v.y == bad) ? undefined_f() : v.y;
-        v.z = (v.z == bad) ? undefined_f() : v.z;
-        v.w = (v.w == bad) ? undefined_f() : v.w;
-    } else {
-        v.x = isnan(v.x) ? bad : v.x;              // :1788
-        v.y = isnan(v.y) ? bad : v.y;
-        v.z = isnan(v.z) ? bad : v.z;
-        v.w = isnan(v.w) ? bad : v.w;
-    }
-    return v;
+    const float to = TO_NAN ? undefined_f() : bad;
+    const bool hx = hit<TO_NAN>(v.x, bad), hy = hit<TO_NAN>(v.y, bad), hz = hit<TO_NAN>(v.z, bad), hw = hit<TO_NAN>(v.w, bad);
+    v.x = hx ? to : v.x;
+    v.y = hy ? to : v.y;
+    v.z = hz ? to : v.z;
+    v.w = hw ? to : v.w;
+    return hx || hy || hz || hw;
 }
 
 template <bool TO_NAN>
@@ -43,15 +43,18 @@ __global__ void __launch_bounds__(kBlock) replace_kernel(float* __restrict__ d, 
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     for (; i + 3 * stride < n4; i += 4 * stride) {
         float4 a = d4[i], b = d4[i + stride], c = d4[i + 2 * stride], e = d4[i + 3 * stride];
-        d4[i] = replace4<TO_NAN>(a, bad);
-        d4[i + stride] = replace4<TO_NAN>(b, bad);
-        d4[i + 2 * stride] = replace4<TO_NAN>(c, bad);
-        d4[i + 3 * stride] = replace4<TO_NAN>(e, bad);
+        if (replace4<TO_NAN>(a, bad)) d4[i] = a;
+        if (replace4<TO_NAN>(b, bad)) d4[i + stride] = b;
+        if (replace4<TO_NAN>(c, bad)) d4[i + 2 * stride] = c;
+        if (replace4<TO_NAN>(e, bad)) d4[i + 3 * stride] = e;
     }
-    for (; i < n4; i += stride) d4[i] = replace4<TO_NAN>(d4[i], bad);
+    for (; i < n4; i += stride) {
+        float4 a = d4[i];
+        if (replace4<TO_NAN>(a, bad)) d4[i] = a;
+    }
     for (size_t j = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
         const float v = d[j];
-        d[j] = TO_NAN ? ((v == bad) ? undefined_f() : v) : (isnan(v) ? bad : v);
+        if (hit<TO_NAN>(v, bad)) d[j] = TO_NAN ? undefined_f() : bad;
     }
 }
 
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(kBlock) replace_scalar_kernel(float* __restric
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const float v = d[i];
-        d[i] = TO_NAN ? ((v == bad) ? undefined_f() : v) : (isnan(v) ? bad : v);
+        if (hit<TO_NAN>(v, bad)) d[i] = TO_NAN ? undefined_f() : bad;
     }
 }
 

@@ -432,7 +432,9 @@ __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
 // the CU's L1).  One workgroup barrier per sweep remains (border pass, convergence test).
 constexpr int kV2Waves = 16;
 constexpr int kV2Threads = kV2Waves * kWave;
-constexpr int kCh = 16;            // skewed columns per chunk
+constexpr int kCh = 16;            // skewed columns per chunk (16 or 32): one global-memory event per chunk
+constexpr int kRowsPerIt = kWave / kCh;      // rows one wave-wide load / store of a chunk covers
+constexpr int kChunksPerWord = 32 / kCh;     // chunks per 32-column mask word
 constexpr int kRingW = 2 * kCh;    // ring width (two chunks)
 constexpr int kPitch = kRingW + 1; // conflict-free: bank = (lane + x') mod 32
 constexpr int kMaxBands = 4096;
@@ -448,6 +450,24 @@ struct Fill2dV2Args {
     unsigned long long maxLoop;
     int sumAlgo;
 };
+
+// Flags of the LDS hand-off.  The LDS executes one wave's operations in issue order and is coherent within the CU, so a
+// flag written after the data (and read before it) needs no fence -- and must not get one: a release / acquire at
+// workgroup scope makes the compiler wait for ALL outstanding vector-memory operations (s_waitcnt vmcnt(0)), i.e. for the
+// chunk prefetch that was issued a moment ago, once per event.  Compiler barriers keep the program order.
+__device__ __forceinline__ void lds_publish(unsigned int* flag, unsigned int value)
+{
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned int lds_observe(const unsigned int* flag)
+{
+    asm volatile("" ::: "memory");
+    const unsigned int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
+}
 
 // value of lane l-1 (lane 0 keeps its own): one DPP move, "wave_shr:1" (0x138), no LDS round trip
 __device__ __forceinline__ float lane_from_above(float v)
@@ -496,30 +516,54 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f + (size_t)(y0 - 1) * nx, 0, (nrow + 2) * nx * 4u, 0x00020000);
     const uint32_t kOob = 0xFFFFFFFFu;
 
-    // chunk c = skewed columns [c*kCh, c*kCh + kCh) of all 64 rows; lane -> (row 4*it + lane/16, column lane%16)
-    const uint32_t crow = lane >> 4, ccol = lane & 15;
-    float stage[16];
+    // chunk c = skewed columns [c*kCh, c*kCh + kCh) of all 64 rows; lane -> (row kRowsPerIt*it + lane/kCh, column lane%kCh)
+    const uint32_t crow = lane / kCh, ccol = lane % kCh;
+    float stage[kCh];
     auto chunk_off = [&](uint32_t c, uint32_t it, bool store) -> uint32_t {
-        const uint32_t row = 4 * it + crow;
+        const uint32_t row = kRowsPerIt * it + crow;
         const int64_t x = (int64_t)c * kCh + ccol - row;  // unskewed column
         const bool ok = row < nrow && (store ? (x >= 1 && x <= (int64_t)C) : (x >= 0 && x <= (int64_t)nx - 1));
         return ok ? (uint32_t)(((row + 1) * nx + x) * 4u) : kOob;
     };
+    // A chunk is "interior" when every one of its 64 x 16 cells is a cell the sweep updates (all rows of the band exist,
+    // 1 <= x <= C for all of them): no per-lane conditions are needed then, and since a lone wave issues roughly one
+    // instruction per 8-9 clocks, instructions are what the band's time consists of.  Interior chunks address memory as
+    // one per-lane offset plus a scalar offset per row group (buffer soffset) and the LDS ring with immediate offsets.
+    auto interior = [&](uint32_t c) -> bool { return nrow == (uint32_t)kWave && c * kCh >= (uint32_t)kWave && c * kCh + kCh - 1 <= C; };
+    const uint32_t voffLane = ((crow + 1) * nx + ccol - crow) * 4u;           // row crow, chunk 0, column ccol - crow
+    const uint32_t rowStep = (uint32_t)kRowsPerIt * (nx - 1) * 4u;            // next row group: kRowsPerIt rows down, as many columns back
+    float* ringLane = ring + crow * kPitch + ccol;
     auto load_chunk = [&](uint32_t c) {
+        if (interior(c)) {
+            const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it)
+            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+                stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voffLane, s0 + it * rowStep, 0));
+            return;
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
             stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, chunk_off(c, it, false), 0, 0));
     };
     auto commit_chunk = [&](uint32_t c) {
+        float* dst = ringLane + ((c * kCh) & kCh);
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it) ring[(4 * it + crow) * kPitch + ((c * kCh + ccol) & (kRingW - 1))] = stage[it];
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) dst[kRowsPerIt * it * kPitch] = stage[it];
     };
     auto flush_chunk = [&](uint32_t c) {
-        float v[16];
+        float v[kCh];
+        const float* src = ringLane + ((c * kCh) & kCh);
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it) v[it] = ring[(4 * it + crow) * kPitch + ((c * kCh + ccol) & (kRingW - 1))];
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) v[it] = src[kRowsPerIt * it * kPitch];
+        if (interior(c)) {
+            const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it)
+            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
+            return;
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
     };
     auto load_block = [&](uint32_t rowInBuf, uint32_t k) {  // 64 columns of the row above (0) / below (nrow + 1)
@@ -544,16 +588,16 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     const bool inGlobal = b > 0 && (b % kV2Waves) == 0;
     auto wait_above = [&](uint32_t k) {
         const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
-        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
     };
     // block k (columns 64k .. 64k+63) of the row above from the hand-off of band b - 1
     auto take_above = [&](uint32_t k) -> float {
         const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
         // a larger band tag means the producer has finished band b - 1 long ago (its data stay in the other parity slot)
-        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
         const float v = handIn[(64 * k + lane) % kHandW];
         if (lane == 0)
-            __hip_atomic_store(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64));
         return v;
     };
 
@@ -583,37 +627,16 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             if (outGlobal && xpc > L) {  // stores of the previous event (chunk c - 2) have landed: columns < 16 (c - 1) - L of the last row
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0 && xpc - kCh > L)
-                    __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L));
             }
-            flush_chunk(c - 1);      // results of the chunk just finished -> global (never waited for)
-            commit_chunk(c + 1);     // loaded one event ago, into the ring slot the flush has just read
-            load_chunk(c + 2);       // consumed at the next event
-            if ((c & 1) == 0) {      // x' is a multiple of 32: every lane switches mask words now
+            // Order matters: vector-memory results come back in issue order, so waiting for a load also waits for every
+            // load issued before it.  The small loads (mask word, 64-column blocks of the rows above / below) go first,
+            // the 16 loads of the chunk prefetch last: whatever the compiler makes of the small ones, it never has to wait
+            // for the prefetch before the next event.
+            if ((c % kChunksPerWord) == 0) {      // x' is a multiple of 32: every lane switches mask words now
                 mw = mwN;
                 mwN = mwLd;
-                mwLd = mrow[min(c / 2 + 2, mws - 1)];
-            }
-            // publish how far the last row has got, and do not run more than the hand-off window ahead of the band below
-            if (xpc > L && !outGlobal) {
-                if (lane == 0)
-                    __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (hasBelow) {
-                    const unsigned int limit = xpc + kCh - L;  // columns < limit are written during this chunk
-                    while (true) {
-                        const unsigned int cns = __hip_atomic_load(&hand.consumed[slotOut], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (limit <= (cns & 0x7FFFFu) + kHandW) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-            }
-            // row above: lane 0 is at column x'
-            if ((xpc & 63) == 0) {
-                if (b == 0 || inGlobal) upCur = upLd;  // from global, requested two chunks ago
-                else upCur = take_above(xpc >> 6);
-            }
-            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
-                if (inGlobal) wait_above((xpc + 2 * kCh) >> 6);
-                upLd = load_block(0, (xpc + 2 * kCh) >> 6);
+                mwLd = mrow[min(c / kChunksPerWord + 2, mws - 1)];
             }
             // row below: the last lane is at column x' - L
             if (downLdValid) { downB = downLd; downLdValid = false; }
@@ -621,8 +644,107 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 const uint32_t k = (xpc + 3 * kCh - L) >> 6;
                 if (k > downIssued) { downLd = load_block(nrow + 1, k); downIssued = k; downLdValid = true; }
             }
+            // row above: lane 0 is at column x'
+            if ((xpc & 63) == 0 && (b == 0 || inGlobal)) upCur = upLd;  // from global, requested two chunks ago
+            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
+                if (inGlobal) wait_above((xpc + 2 * kCh) >> 6);
+                upLd = load_block(0, (xpc + 2 * kCh) >> 6);
+            }
+            flush_chunk(c - 1);      // results of the chunk just finished -> global (never waited for)
+            commit_chunk(c + 1);     // loaded one event ago, into the ring slot the flush has just read
+            // publish how far the last row has got, and do not run more than the hand-off window ahead of the band below
+            if (xpc > L && !outGlobal) {
+                if (lane == 0)
+                    lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
+                if (hasBelow) {
+                    const unsigned int limit = xpc + kCh - L;  // columns < limit are written during this chunk
+                    while (true) {
+                        const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
+                        if (limit <= (cns & 0x7FFFFu) + kHandW) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            if ((xpc & 63) == 0 && !(b == 0 || inGlobal)) upCur = take_above(xpc >> 6);
+            load_chunk(c + 2);       // consumed at the next event
         }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCh - 1, xpEnd);
+        if (interior(c) && xpc > (uint32_t)kWave) {
+            // ---- every lane is at a cell the sweep updates, at x >= 2: no range tests, "left" is the previous result
+            const uint32_t half = xpc & kCh;
+            float* rc = ringRow + half;
+            const float* rb = ringBelow + half;
+            const uint32_t rNext = (half ^ kCh);
+            const uint32_t sh0 = xpc & 31, up0 = xpc & 63;
+            const uint32_t kSwitch = (L - xpc) & 63;
+            const bool switches = kSwitch < (uint32_t)kCh;  // xpc + kSwitch > L holds: xpc >= 64 > L - kSwitch
+            const int dBase = (int)((xpc - L) & 63);
+#pragma unroll
+            for (int k = 0; k < kCh; ++k) {
+                const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
+                float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                const float center = prevRight;
+                float up = lane_from_above(prevRes);
+                const float upFirst = lane_value(upCur, (int)(up0 + k));
+                if (lane == 0) up = upFirst;
+                const float dsel = (switches && (uint32_t)k >= kSwitch) ? downB : downA;
+                const float downLast = lane_value(dsel, (dBase + k) & 63);
+                if (lane == L) down = downLast;
+                const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
+                const float e = (float)((double)(((right + prevRes) + down) + up) * 0.25 - (double)center);  // interpolation.c:1332
+                const float res = center + e * wv;                                                           // :1333
+                rc[k] = res;
+                prevRes = res;
+                if (check && (fabsf(e * wv) > crtest)) bad = 1;                                              // :1349
+                prevRight = right;
+            }
+            if (switches) downA = downB;
+            if (lane < (uint32_t)kCh) handOut[(xpc + lane - L) % kHandW] = ring[L * kPitch + ((xpc + lane) & (kRingW - 1))];
+            continue;
+        }
+        if (xpc >= 1 && xpc + kCh - 1 <= xpEnd) {
+            // ---- a whole chunk: 16 steps unrolled, everything that is the same for all lanes in scalar registers, no
+            // branches (inactive lanes rewrite the ring slot with its own value), hand-off copied once at the end
+            const uint32_t half = xpc & kCh;                                   // ring half this chunk lives in
+            float* rc = ringRow + half;
+            const float* rb = ringBelow + half;
+            const uint32_t rNext = (half ^ kCh);                               // first column of the other half
+            const int x0 = (int)xpc - (int)lane;
+            const uint32_t sh0 = xpc & 31, up0 = xpc & 63;
+            const uint32_t kSwitch = (L - xpc) & 63;                           // step at which the last lane enters the next 64-column block
+            const bool switches = kSwitch < (uint32_t)kCh && xpc + kSwitch > L;
+            const int dBase = (int)((xpc - L) & 63);                           // column of the last lane within its block (valid when xpc >= L)
+#pragma unroll
+            for (int k = 0; k < kCh; ++k) {
+                const int x = x0 + k;
+                const bool active = rowValid && x >= 1 && x <= (int)C;
+                const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
+                float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                const float center = prevRight;
+                float up = lane_from_above(prevRes);
+                const float upFirst = lane_value(upCur, (int)(up0 + k));
+                if (lane == 0) up = upFirst;
+                const bool afterSwitch = switches && (uint32_t)k >= kSwitch;
+                const float dsel = afterSwitch ? downB : downA;
+                const float downLast = lane_value(dsel, (xpc + k >= L) ? ((dBase + k) & 63) : 0);
+                if (lane == L) down = downLast;
+                const float left = (x == 1) ? left0 : prevRes;
+                const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
+                const float e = (float)((double)(((right + left) + down) + up) * 0.25 - (double)center);  // interpolation.c:1332
+                const float res = active ? center + e * wv : center;                                      // :1333
+                rc[k] = res;
+                prevRes = res;
+                if (check && active && (fabsf(e * wv) > crtest)) bad = 1;                                 // :1349
+                prevRight = right;
+            }
+            if (switches) downA = downB;
+            {   // the band below reads its "up" values from the hand-off: lanes 0..15 copy one column of the last row each
+                const uint32_t xpk = xpc + lane;
+                const int xk = (int)xpk - (int)L;
+                if (lane < (uint32_t)kCh && xk >= 1 && xk <= (int)C) handOut[(uint32_t)xk % kHandW] = ring[L * kPitch + (xpk & (kRingW - 1))];
+            }
+            continue;
+        }
         for (uint32_t xp = xp0; xp <= xp1; ++xp) {
             if (xp > L && ((xp - L) & 63) == 0) downA = downB;  // the last lane enters block (x' - L) / 64
             const int64_t x = (int64_t)xp - lane;
@@ -651,7 +773,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     }
     flush_chunk(nChunks - 1);
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, C + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
 }
 
 __global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
@@ -887,6 +1009,8 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
 // A cell that starts being updated in sweep s is updated in every sweep s .. s + repeat - 1 (its neighbours never
 // lose their weight), so "r[p] < repeat" in sweep l is "p is not in U as of sweep l - repeat": U is kept for the
 // last repeat + 1 sweeps instead of a counter per cell.  Weights travel as floats (0, 1, setWeight: all exact).
+constexpr int kCreepWaves = 8;    // 8 waves x 256 registers: the creep step keeps more state than the 128 registers of a 16-wave workgroup hold
+constexpr int kCreepThreads = kCreepWaves * kWave;
 constexpr int kHandWC = 128;  // hand-off window of the creep kernel: values and weight codes share the LDS left
 
 struct CreepV2Args {
@@ -900,6 +1024,7 @@ struct CreepV2Args {
     uint32_t repeat;
     int setWeight;     // >= 0
     int sumAlgo;
+    int skipIdle;
 };
 
 struct HandoffC {
@@ -917,7 +1042,7 @@ __device__ __forceinline__ uint32_t lane_from_below(uint32_t v)
 
 __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ maskD, const uint32_t* __restrict__ uOld,
                            const uint32_t* __restrict__ uHist, uint32_t* __restrict__ uNew, float* ring, HandoffC hand, uint32_t b,
-                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, int& changed)
+                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, bool skipIdle, int& changed)
 {
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -940,29 +1065,50 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     // weight of border column 0 of my row: skewed column = lane
     const float wLeft0 = ((drow[lane >> 5] >> (lane & 31)) & 1u) ? swf : 0.f;
 
-    const uint32_t crow = lane >> 4, ccol = lane & 15;
-    float stage[16];
+    const uint32_t crow = lane / kCh, ccol = lane % kCh;
+    float stage[kCh];
     auto chunk_off = [&](uint32_t c, uint32_t it, bool store) -> uint32_t {
-        const uint32_t row = 4 * it + crow;
+        const uint32_t row = kRowsPerIt * it + crow;
         const int64_t x = (int64_t)c * kCh + ccol - row;
         const bool ok = row < nrow && (store ? (x >= 1 && x <= (int64_t)C) : (x >= 0 && x <= (int64_t)nx - 1));
         return ok ? (uint32_t)(((row + 1) * nx + x) * 4u) : kOob;
     };
+    // interior chunks: lean addressing, see fill2d_band
+    auto interior = [&](uint32_t c) -> bool { return nrow == (uint32_t)kWave && c * kCh >= (uint32_t)kWave && c * kCh + kCh - 1 <= C; };
+    const uint32_t voffLane = ((crow + 1) * nx + ccol - crow) * 4u;           // row crow, chunk 0, column ccol - crow
+    const uint32_t rowStep = (uint32_t)kRowsPerIt * (nx - 1) * 4u;            // next row group: kRowsPerIt rows down, as many columns back
+    float* ringLane = ring + crow * kPitch + ccol;
     auto load_chunk = [&](uint32_t c) {
+        if (interior(c)) {
+            const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it)
+            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+                stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voffLane, s0 + it * rowStep, 0));
+            return;
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
             stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, chunk_off(c, it, false), 0, 0));
     };
     auto commit_chunk = [&](uint32_t c) {
+        float* dst = ringLane + ((c * kCh) & kCh);
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it) ring[(4 * it + crow) * kPitch + ((c * kCh + ccol) & (kRingW - 1))] = stage[it];
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) dst[kRowsPerIt * it * kPitch] = stage[it];
     };
     auto flush_chunk = [&](uint32_t c) {
-        float v[16];
+        float v[kCh];
+        const float* src = ringLane + ((c * kCh) & kCh);
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it) v[it] = ring[(4 * it + crow) * kPitch + ((c * kCh + ccol) & (kRingW - 1))];
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) v[it] = src[kRowsPerIt * it * kPitch];
+        if (interior(c)) {
+            const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
-        for (uint32_t it = 0; it < 16; ++it)
+            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
+            return;
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
     };
     auto load_block = [&](uint32_t rowInBuf, uint32_t k) {
@@ -976,8 +1122,8 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         return ((d >> (col & 31)) & 1u) ? swf : (float)((u >> (col & 31)) & 1u);
     };
 
-    const uint32_t slotOut = (b % kV2Waves) * 2 + ((b / kV2Waves) & 1);
-    const uint32_t slotIn = ((b - 1) % kV2Waves) * 2 + (((b - 1) / kV2Waves) & 1);
+    const uint32_t slotOut = (b % kCreepWaves) * 2 + ((b / kCreepWaves) & 1);
+    const uint32_t slotIn = ((b - 1) % kCreepWaves) * 2 + (((b - 1) / kCreepWaves) & 1);
     float* handOut = hand.data + slotOut * kHandWC;
     unsigned char* handOutW = hand.wcode + slotOut * kHandWC;
     const float* handIn = hand.data + slotIn * kHandWC;
@@ -989,11 +1135,11 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     // every 16th boundary goes through global memory (see fill2d_band): values from the flushed row, weights from the
     // D mask and this sweep's U words of that row (skew 63), which the producing band stores at every event
     const bool hasBelow = y0 + nrow < ny - 1;
-    const bool outGlobal = hasBelow && (b % kV2Waves) == kV2Waves - 1;
-    const bool inGlobal = b > 0 && (b % kV2Waves) == 0;
+    const bool outGlobal = hasBelow && (b % kCreepWaves) == kCreepWaves - 1;
+    const bool inGlobal = b > 0 && (b % kCreepWaves) == 0;
     auto wait_above = [&](uint32_t k) {
         const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
-        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
     };
     auto load_wblock_above = [&](uint32_t k) -> float {
         const uint32_t xs = min(64 * k + lane, nx - 1) + (kWave - 1);
@@ -1002,12 +1148,12 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     };
     auto take_above = [&](uint32_t k, float& fv, float& wv) {
         const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
-        while (__hip_atomic_load(&hand.produced[slotIn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
         fv = handIn[(64 * k + lane) % kHandWC];
         const unsigned int code = handInW[(64 * k + lane) % kHandWC];
         wv = (code == 2u) ? swf : (float)code;
         if (lane == 0)
-            __hip_atomic_store(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64));
     };
 
     load_chunk(0);
@@ -1041,44 +1187,20 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 if (xpc > L) {  // stores of the previous event have landed: columns < 16 (c - 1) - L of the last row, values and U bits
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0 && xpc - kCh > L)
-                        __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L));
                 }
-                if (rowValid) nrowU[(c - 1) / 2] = un;  // the (partial) word of the chunk just finished
+                if (rowValid) nrowU[(c - 1) / kChunksPerWord] = un;  // the (partial) word of the chunk just finished
             }
-            flush_chunk(c - 1);
-            commit_chunk(c + 1);
-            load_chunk(c + 2);
-            if ((c & 1) == 0) {  // x' is a multiple of 32: the finished U word goes out, every lane switches words
-                if (rowValid) nrowU[c / 2 - 1] = un;
+            // small loads first, the chunk prefetch last (see fill2d_band)
+            if ((c % kChunksPerWord) == 0) {  // x' is a multiple of 32: the finished U word goes out, every lane switches words
+                if (rowValid) nrowU[c / kChunksPerWord - 1] = un;
                 un = 0;
-                const uint32_t nxt = min(c / 2 + 2, wLast);
+                const uint32_t nxt = min(c / kChunksPerWord + 2, wLast);
                 dw = dwN; dwN = dwLd; dwLd = drow[nxt];
                 uw = uwN; uwN = uwLd; uwLd = urow[nxt];
                 hw = hwN; hwN = hwLd; hwLd = hrow ? hrow[nxt] : 0u;
                 ddw = ddwN; ddwN = lane_from_below(dwN);
                 duw = duwN; duwN = lane_from_below(uwN);
-            }
-            if (xpc > L && !outGlobal) {
-                if (lane == 0)
-                    __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, xpc - L), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (hasBelow) {
-                    const unsigned int limit = xpc + kCh - L;
-                    while (true) {
-                        const unsigned int cns = __hip_atomic_load(&hand.consumed[slotOut], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (limit <= (cns & 0x7FFFFu) + kHandWC) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-            }
-            if ((xpc & 63) == 0) {
-                if (b == 0 || inGlobal) { upCur = upLd; upWCur = upWLd; }
-                else take_above(xpc >> 6, upCur, upWCur);
-            }
-            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
-                const uint32_t k = (xpc + 2 * kCh) >> 6;
-                if (inGlobal) wait_above(k);
-                upLd = load_block(0, k);
-                upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
             }
             if (downLdValid) { downB = downLd; downWB = downWLd; downLdValid = false; }
             if (xpc + 3 * kCh > L) {
@@ -1090,8 +1212,107 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                     downLdValid = true;
                 }
             }
+            if ((xpc & 63) == 0 && (b == 0 || inGlobal)) { upCur = upLd; upWCur = upWLd; }
+            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
+                const uint32_t k = (xpc + 2 * kCh) >> 6;
+                if (inGlobal) wait_above(k);
+                upLd = load_block(0, k);
+                upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
+            }
+            flush_chunk(c - 1);
+            commit_chunk(c + 1);
+            if (xpc > L && !outGlobal) {
+                if (lane == 0)
+                    lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
+                if (hasBelow) {
+                    const unsigned int limit = xpc + kCh - L;
+                    while (true) {
+                        const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
+                        if (limit <= (cns & 0x7FFFFu) + kHandWC) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            if ((xpc & 63) == 0 && !(b == 0 || inGlobal)) take_above(xpc >> 6, upCur, upWCur);
+            load_chunk(c + 2);
         }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCh - 1, xpEnd);
+        // A chunk in which no row has a cell that may still change (undefined on entry and not yet updated `repeat` times:
+        // neither D nor H) is passed over: nothing is computed, the state the next chunk and the band below need is taken
+        // from the ring and the masks.  After the first sweeps that is most of the field.
+        const uint32_t chunkBits = ((xp1 - xp0 + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (xp1 - xp0 + 1)) - 1u)) << (xp0 & 31);
+        if (skipIdle && !__any(rowValid && ((~dw & ~hw & chunkBits) != 0u))) {
+            for (uint32_t xp = xp0; xp <= xp1; ++xp)
+                if (xp > L && ((xp - L) & 63) == 0) { downA = downB; downWA = downWB; }
+            un |= uw & chunkBits;  // U is carried over unchanged
+            {   // the band below still needs this stretch of the last row: lanes 0..15 copy one column each
+                const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dw, (int)L), uL = (uint32_t)__builtin_amdgcn_readlane((int)uw, (int)L);
+                const uint32_t xpk = xp0 + lane;
+                const int64_t xk = (int64_t)xpk - L;
+                if (xpk <= xp1 && xk >= 1 && xk <= (int64_t)C) {
+                    handOut[(uint32_t)xk % kHandWC] = ring[L * kPitch + (xpk & (kRingW - 1))];
+                    handOutW[(uint32_t)xk % kHandWC] = ((dL >> (xpk & 31)) & 1u) ? 2 : ((uL >> (xpk & 31)) & 1u);
+                }
+            }
+            prevRes = ringRow[xp1 & (kRingW - 1)];
+            prevW = ((dw >> (xp1 & 31)) & 1u) ? swf : (float)((uw >> (xp1 & 31)) & 1u);
+            prevRight = ringRow[(xp1 + 1) & (kRingW - 1)];
+            continue;
+        }
+        if (interior(c) && xpc > (uint32_t)kWave) {
+            // ---- every lane is at an interior cell with x >= 2: unrolled, no range tests, mask bits as 17-bit windows
+            const uint32_t half = xpc & kCh;
+            float* rc = ringRow + half;
+            const float* rb = ringBelow + half;
+            const uint32_t rNext = (half ^ kCh);
+            const uint32_t sh0 = xpc & 31, up0 = xpc & 63;
+            const uint32_t kSwitch = (L - xpc) & 63;
+            const bool switches = kSwitch < (uint32_t)kCh;
+            const int dBase = (int)((xpc - L) & 63);
+            // bit k: the cell of step k, bit k + 1: its right neighbour (own row) / the cell below (row of lane + 1)
+            const uint32_t d17 = __builtin_amdgcn_alignbit(dwN, dw, sh0), u17 = __builtin_amdgcn_alignbit(uwN, uw, sh0), h16 = hw >> sh0;
+            const uint32_t dd17 = __builtin_amdgcn_alignbit(ddwN, ddw, sh0), du17 = __builtin_amdgcn_alignbit(duwN, duw, sh0);
+            uint32_t newBits = 0;
+#pragma unroll
+            for (int k = 0; k < kCh; ++k) {
+                const bool cD = (d17 >> k) & 1u, cU = (u17 >> k) & 1u, cH = (h16 >> k) & 1u;
+                const float wr = ((d17 >> (k + 1)) & 1u) ? swf : (((u17 >> (k + 1)) & 1u) ? 1.f : 0.f);
+                float wd = ((dd17 >> (k + 1)) & 1u) ? swf : (((du17 >> (k + 1)) & 1u) ? 1.f : 0.f);
+                const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
+                float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                const float center = prevRight;
+                float up = lane_from_above(prevRes), wu = lane_from_above(prevW);
+                const float upFirst = lane_value(upCur, (int)(up0 + k)), wuFirst = lane_value(upWCur, (int)(up0 + k));
+                if (lane == 0) { up = upFirst; wu = wuFirst; }
+                const bool after = switches && (uint32_t)k >= kSwitch;
+                const float dsel = after ? downB : downA, dwsel = after ? downWB : downWA;
+                const float downLast = lane_value(dsel, (dBase + k) & 63), wdLast = lane_value(dwsel, (dBase + k) & 63);
+                if (lane == L) { down = downLast; wd = wdLast; }
+                const float wsum = ((wr + prevW) + wd) + wu;                                        // :1445
+                const bool act = !cD && !cH && wsum != 0.f;                                         // :1443, :1446
+                float v = center + (((wr * right + prevW * prevRes) + wd * down) + wu * up);        // :1451
+                v = v / (1.f + wsum);                                                               // :1452
+                const float res = act ? v : center;
+                const bool newU = cU || act;
+                rc[k] = res;
+                if (act) changed = 1;
+                newBits |= (newU ? 1u : 0u) << k;
+                prevRes = res;
+                prevW = cD ? swf : (newU ? 1.f : 0.f);
+                prevRight = right;
+            }
+            if (switches) { downA = downB; downWA = downWB; }
+            un |= newBits << sh0;
+            {
+                const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)d17, (int)L), nL = (uint32_t)__builtin_amdgcn_readlane((int)newBits, (int)L);
+                if (lane < (uint32_t)kCh) {
+                    const uint32_t xk = xpc + lane - L;
+                    handOut[xk % kHandWC] = ring[L * kPitch + ((xpc + lane) & (kRingW - 1))];
+                    handOutW[xk % kHandWC] = ((dL >> lane) & 1u) ? 2 : ((nL >> lane) & 1u);
+                }
+            }
+            continue;
+        }
         for (uint32_t xp = xp0; xp <= xp1; ++xp) {
             if (xp > L && ((xp - L) & 63) == 0) { downA = downB; downWA = downWB; }
             const int64_t x = (int64_t)xp - lane;
@@ -1135,22 +1356,22 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         }
     }
     flush_chunk(nChunks - 1);
-    if (rowValid) nrowU[(nChunks - 1) / 2] = un;
+    if (rowValid) nrowU[(nChunks - 1) / kChunksPerWord] = un;
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, C + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
 }
 
-__global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
+__global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned long long shUndef;
     __shared__ float shDefault;
     float* rings = smem;
     HandoffC hand;
-    hand.data = smem + kV2Waves * kWave * kPitch;
-    hand.wcode = reinterpret_cast<unsigned char*>(hand.data + kV2Waves * 2 * kHandWC);
-    hand.produced = reinterpret_cast<unsigned int*>(hand.wcode + kV2Waves * 2 * kHandWC);
-    hand.consumed = hand.produced + kV2Waves * 2;
+    hand.data = smem + kCreepWaves * kWave * kPitch;
+    hand.wcode = reinterpret_cast<unsigned char*>(hand.data + kCreepWaves * 2 * kHandWC);
+    hand.produced = reinterpret_cast<unsigned int*>(hand.wcode + kCreepWaves * 2 * kHandWC);
+    hand.consumed = hand.produced + kCreepWaves * 2;
     const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
     const size_t total = (size_t)nx * ny;
     const size_t maskWords = (size_t)ny * mws;
@@ -1161,7 +1382,7 @@ __global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 
     unsigned long long nUndef = 0;
-    const double sum = scan_order_sum<kV2Threads>(f, total, a.useDefault ? 2 : 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumAlgo);
+    const double sum = scan_order_sum<kCreepThreads>(f, total, a.useDefault ? 2 : 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumAlgo);
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
@@ -1178,7 +1399,7 @@ __global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
     const float swf = (float)a.setWeight;
 
     // first guess and the D mask (:1408-1421): one wave per row, ballot words in the row's skew
-    for (uint32_t y = wave; y < ny; y += kV2Waves) {
+    for (uint32_t y = wave; y < ny; y += kCreepWaves) {
         float* row = f + (size_t)y * nx;
         const uint32_t l = (y == 0 || y == ny - 1) ? 0u : ((y - 1) & (kWave - 1));
         uint32_t* mrow = maskD + (size_t)y * mws;
@@ -1204,14 +1425,14 @@ __global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
     int changedInLoop = 1;
     while (repeat > 0 && changedInLoop && l < nDef) {  // :1430 (nothing has r < repeat when repeat is 0)
         l++;
-        if (threadIdx.x < kV2Waves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
+        if (threadIdx.x < kCreepWaves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
         __syncthreads();
         const uint32_t* uOld = maskU + (size_t)((l - 1) % a.gens) * maskWords;
         const uint32_t* uHist = (l > repeat) ? maskU + (size_t)((l - repeat) % a.gens) * maskWords : nullptr;
         uint32_t* uNew = maskU + (size_t)(l % a.gens) * maskWords;
         int mine = 0;
-        for (uint32_t b = wave; b < nBands; b += kV2Waves)
-            creep_band(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, mine);
+        for (uint32_t b = wave; b < nBands; b += kCreepWaves)
+            creep_band(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine);
         changedInLoop = __syncthreads_or(mine);
     }
     // borders (:1464-1489): undefined border cells have r = 0 < repeat in every round, defined ones never change
@@ -1226,7 +1447,7 @@ __global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
         return (uFin[(size_t)y * mws + ((x + sk) >> 5)] >> ((x + sk) & 31)) & 1u;
     };
     for (uint32_t k = 0; k < repeat; ++k) {
-        for (uint32_t y = 1 + threadIdx.x; y < nym1; y += kV2Threads) {
+        for (uint32_t y = 1 + threadIdx.x; y < nym1; y += kCreepThreads) {
             const size_t row = (size_t)y * nx;
             if (!defined(y, 0)) {
                 const int wn = w_interior(y, 1);
@@ -1240,7 +1461,7 @@ __global__ void __launch_bounds__(kV2Threads) creepfill_kernel_v2(CreepV2Args a)
             }
         }
         __syncthreads();
-        for (uint32_t x = threadIdx.x; x < nx; x += kV2Threads) {
+        for (uint32_t x = threadIdx.x; x < nx; x += kCreepThreads) {
             const size_t bo = (size_t)nym1 * nx + x;
             const bool edge = (x == 0 || x == nxm1);  // the neighbour is a border cell of the column loop above: w = 1 if it was undefined
             if (!defined(0, x)) {
@@ -1355,10 +1576,11 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         a.repeat = repeat;
         a.setWeight = (int)setWeight;
         a.sumAlgo = tuning("SUM_ALGO", 1);
-        constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandWC * (sizeof(float) + 1) +
-                                    (size_t)kV2Waves * 4 * sizeof(unsigned int);
+        a.skipIdle = tuning("CREEP_SKIP", 1);
+        constexpr size_t ldsBytes = (size_t)kCreepWaves * kWave * kPitch * sizeof(float) + (size_t)kCreepWaves * 2 * kHandWC * (sizeof(float) + 1) +
+                                    (size_t)kCreepWaves * 4 * sizeof(unsigned int);
         allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
-        creepfill_kernel_v2<<<dim3((uint32_t)nz), kV2Threads, ldsBytes, stream>>>(a);
+        creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);
         FA_HIP(hipGetLastError());
         collect_stats(stats, nz, h_nChanged, stream, what);
         return;

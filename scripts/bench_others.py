@@ -57,7 +57,15 @@ def main():
     emit("rotate_direction nz=%d 2000x2000" % nz, ms, mn, nz * 8 * n + 8 * n, nz * n)
     ms, mn = timed(torch, lambda: fa.bad2nan_device(d_u.data_ptr(), d_u.numel(), 1e30, st))
     emit("bad2nan %d floats" % d_u.numel(), ms, mn, 8 * d_u.numel(), d_u.numel())
-    del d_u, d_v, d_in, d_out
+    # --- typed slice edges (n1) and 1-D blends (n4) on the same 800 M values
+    d_s = (d_u * 100).to(torch.int16)
+    ms, mn = timed(torch, lambda: fa.data2interpolation_device(d_s.data_ptr(), fa.CDM_SHORT, d_s.numel(), -32767.0, d_u.data_ptr(), st))
+    emit("data2interpolation short->float %d values" % d_s.numel(), ms, mn, 6 * d_s.numel(), d_s.numel())
+    ms, mn = timed(torch, lambda: fa.interpolation2data_device(d_u.data_ptr(), d_u.numel(), fa.CDM_SHORT, -32767.0, d_s.data_ptr(), st))
+    emit("interpolation2data float->short %d values" % d_s.numel(), ms, mn, 6 * d_s.numel(), d_s.numel())
+    ms, mn = timed(torch, lambda: fa.get_values_1d_device(fa.BLEND_LINEAR, d_u.data_ptr(), d_v.data_ptr(), d_in.data_ptr(), d_u.numel(), 0., 1., .3, st))
+    emit("linear blend of two fields, %d values" % d_u.numel(), ms, mn, 12 * d_u.numel(), d_u.numel())
+    del d_u, d_v, d_in, d_out, d_s
     # --- C4: forward methods, 3600x1800 -> 1500x1500 Lambert
     fw = workloads.ForwardLambert()
     x, y = fw.source_in_target_metres()

@@ -142,7 +142,7 @@ extern "C" {
 
 const char* fimex_amd_last_error(void) { return g_lastError.c_str(); }
 
-int fimex_amd_abi_version(void) { return 100; }
+int fimex_amd_abi_version(void) { return 110; }  // 1.10: typed slices, projections, coordinate search, 1-D blends added to 1.00
 
 int fimex_amd_device_count(void) { return usable_device_count(); }
 

@@ -19,6 +19,8 @@ namespace {
 constexpr size_t kPinBytes = (size_t)64 << 20;   // pinned staging per slot and direction
 constexpr size_t kDevFloatBytes = (size_t)128 << 20;  // float scratch per slot and direction (typed slices)
 constexpr int kSlots = 3;
+constexpr size_t kPiece = (size_t)8 << 20;            // a slot's transfer goes in pieces: host memcpy of one overlaps the DMA of the other
+constexpr int kPieces = (int)(kPinBytes / kPiece);
 constexpr int kMaxCached = 4;
 
 // memcpy on several threads: the workers live as long as the pipe
@@ -91,6 +93,7 @@ struct Slot {
     float *dFIn = nullptr, *dFOut = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t piece[kPieces] = {};   // piece p of the result has arrived in pinOut
 };
 
 class HostPipe {
@@ -106,6 +109,7 @@ public:
             FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFOut), kDevFloatBytes));
             FA_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             FA_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+            for (hipEvent_t& e : s.piece) FA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
     }
     ~HostPipe()
@@ -119,6 +123,7 @@ public:
             if (s.dFIn) (void)hipFree(s.dFIn);
             if (s.dFOut) (void)hipFree(s.dFOut);
             if (s.done) (void)hipEventDestroy(s.done);
+            for (hipEvent_t e : s.piece) if (e) (void)hipEventDestroy(e);
             if (s.stream) (void)hipStreamDestroy(s.stream);
         }
     }
@@ -185,21 +190,33 @@ bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out
     const char* src = static_cast<const char*>(in);
     char* dst = static_cast<char*>(out);
     auto count = [&](size_t c) { return std::min(nzc, nz - c * nzc); };
-    auto finish = [&](size_t c) {
+    auto finish = [&](size_t c) {  // piece by piece: the host copy of one piece overlaps the DMA of the next
         Slot& s = p.slots[c % kSlots];
+        const size_t bytes = count(c) * outSliceBytes;
+        char* to = dst + c * nzc * outSliceBytes;
+        for (size_t off = 0, q = 0; off < bytes; off += kPiece, ++q) {
+            FA_HIP(hipEventSynchronize(s.piece[q]));
+            p.copier.copy(to + off, s.pinOut + off, std::min(kPiece, bytes - off));
+        }
         FA_HIP(hipEventSynchronize(s.done));
-        p.copier.copy(dst + c * nzc * outSliceBytes, s.pinOut, count(c) * outSliceBytes);
     };
     size_t finished = 0;
     try {
         for (size_t c = 0; c < nChunks; ++c) {
             Slot& s = p.slots[c % kSlots];
             if (c >= (size_t)kSlots) { finish(c - kSlots); finished = c - kSlots + 1; }
-            const size_t k = count(c);
-            p.copier.copy(s.pinIn, src + c * nzc * inSliceBytes, k * inSliceBytes);
-            FA_HIP(hipMemcpyAsync(s.dRawIn, s.pinIn, k * inSliceBytes, hipMemcpyHostToDevice, s.stream));
+            const size_t k = count(c), inBytes = k * inSliceBytes, outBytes = k * outSliceBytes;
+            const char* from = src + c * nzc * inSliceBytes;
+            for (size_t off = 0; off < inBytes; off += kPiece) {
+                const size_t len = std::min(kPiece, inBytes - off);
+                p.copier.copy(s.pinIn + off, from + off, len);
+                FA_HIP(hipMemcpyAsync(s.dRawIn + off, s.pinIn + off, len, hipMemcpyHostToDevice, s.stream));
+            }
             fn(s.dRawIn, s.dRawOut, s.dFIn, s.dFOut, k, s.stream);
-            FA_HIP(hipMemcpyAsync(s.pinOut, s.dRawOut, k * outSliceBytes, hipMemcpyDeviceToHost, s.stream));
+            for (size_t off = 0, q = 0; off < outBytes; off += kPiece, ++q) {
+                FA_HIP(hipMemcpyAsync(s.pinOut + off, s.dRawOut + off, std::min(kPiece, outBytes - off), hipMemcpyDeviceToHost, s.stream));
+                FA_HIP(hipEventRecord(s.piece[q], s.stream));
+            }
             FA_HIP(hipEventRecord(s.done, s.stream));
         }
         for (size_t c = finished; c < nChunks; ++c) finish(c);

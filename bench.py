@@ -140,7 +140,8 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group(backend="gloo")
     if args.gpus != world and rank == 0:
@@ -227,19 +228,22 @@ def main():
         if dist_on:
             # write-back: RCCL gather of every rank's finished slices to rank 0 over xGMI, outside the metric
             from fimex_amd import sharding
-            dist.barrier()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            # (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)
-            full = sharding.gather_slices(d_out if args.backend == "nccl" else d_out.cpu(), world * nz, dst=0)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter() - tg
-            result["gather"] = {"seconds": tg, "bytes_per_peer": d_out.numel() * 4,
-                                "GBps_into_root": (world - 1) * d_out.numel() * 4 / tg / 1e9,
-                                "note": "point-to-point RCCL sends of every rank's output slices to rank 0 "
-                                        "(fimex_amd/sharding.py); not part of value"}
-            del full
+            try:
+                dist.barrier()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                # (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)
+                full = sharding.gather_slices(d_out if args.backend == "nccl" else d_out.cpu(), world * nz, dst=0)
+                torch.cuda.synchronize()
+                dist.barrier()
+                tg = time.perf_counter() - tg
+                result["gather"] = {"seconds": tg, "bytes_per_peer": d_out.numel() * 4,
+                                    "GBps_into_root": (world - 1) * d_out.numel() * 4 / tg / 1e9,
+                                    "note": "point-to-point RCCL sends of every rank's output slices to rank 0 "
+                                            "(fimex_amd/sharding.py); not part of value"}
+                del full
+            except Exception as e:  # the write-back is reported beside the metric; the metric stands without it
+                result["gather"] = {"seconds": None, "error": repr(e)[:300]}
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         try:
@@ -247,11 +251,14 @@ def main():
         except Exception as e:  # the oracle is only the reported baseline; the GPU numbers stand without it
             result["cpu_baseline"] = {"value": None, "unit": "Mcells/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if dist_on:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

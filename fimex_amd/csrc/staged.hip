@@ -243,14 +243,23 @@ __device__ __forceinline__ void cubic_weights(double f, double w[4])
 
 // STENCIL: 2 bilinear, 4 bicubic; PER: outputs per lane; KMAX: 16-byte chunks per lane and slice
 // (KMAX * 256 * 16 bytes = one LDS buffer).
-template <int STENCIL, int PER, int KMAX>
+// s_waitcnt on vmcnt only (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+    asm volatile("" ::: "memory");
+}
+
+// NBUF: LDS buffers of the slice ring; NBUF - 1 slices are in flight while one is interpolated.  What a workgroup waits
+// for per slice is the latency of its DMA, so the bytes in flight per CU (LDS capacity x (NBUF - 1) / NBUF) set the rate.
+template <int STENCIL, int PER, int KMAX, int NBUF>
 __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers of KMAX*256*4 floats (+ slack), then the row table
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // NBUF buffers of KMAX*256*4 floats (+ slack), then the row table
     constexpr uint32_t kBufFloats = KMAX * kBlock * 4 + 4;
-    float* buf0 = smem;
-    float* buf1 = smem + kBufFloats;
-    uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + 2 * kBufFloats);  // [2 * nr]
+    uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + NBUF * kBufFloats);  // [2 * nr]
 
     // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an L2):
     //   xcdRemap 0: tiles in dispatch order (neighbours on different XCDs) -- the default, measured as good as any;
@@ -344,14 +353,18 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
         for (int j = 0; j < KMAX; ++j) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j]);
     };
 
-    float* cur = buf0;
-    float* nxt = buf1;
-    dma(cur, z0);
+    // prologue: NBUF - 1 slices in flight, the first one landed
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (z0 + i < z1) dma(smem + i * kBufFloats, z0 + i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    uint32_t slot = 0;
     for (uint32_t z = z0; z < z1; ++z) {
-        if (z + 1 < z1) dma(nxt, z + 1);
+        const bool more = z + (NBUF - 1) < z1;
+        if (more) dma(smem + ((slot + NBUF - 1) % NBUF) * kBufFloats, z + (NBUF - 1));  // into the buffer slice z - 1 has left
+        const float* cur = smem + slot * kBufFloats;
         const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, (a.ablate & 2) ? 0u : outBytes);
         const char* curb = reinterpret_cast<const char*>(cur);
         if constexpr (STENCIL == 2) {
@@ -396,22 +409,41 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
             }
         }
-        // the DMA was issued before this slice's PER stores: wait for it, leave the stores in flight
-        if (PER == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // Slice z + 1 must have landed.  Results come back in issue order: behind its DMA are the DMAs of slices
+        // z + 2 .. z + NBUF - 1 and the stores of NBUF - 1 slices, which may all stay in flight.  At the end of the run
+        // (no new DMA issued) only this slice's stores may.
+        if (more) wait_vmcnt<(NBUF - 2) * KMAX + (NBUF - 1) * PER>();
+        else wait_vmcnt<PER>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        float* t = cur; cur = nxt; nxt = t;
+        slot = (slot + 1 == NBUF) ? 0 : slot + 1;
     }
+}
+
+template <int STENCIL, int PER, int KMAX, int NBUF>
+void launch_staged_n(const StagedArgs& a, dim3 grid, hipStream_t stream)
+{
+    constexpr size_t ldsBytes = (size_t)NBUF * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
+    static_assert(ldsBytes <= 160 * 1024, "slice ring does not fit the CU's LDS");
+    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX, NBUF>), ldsBytes);
+    staged_apply<STENCIL, PER, KMAX, NBUF><<<grid, kBlock, ldsBytes, stream>>>(a);
 }
 
 template <int STENCIL, int PER, int KMAX>
 void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
-    constexpr size_t ldsBytes = 2 * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
-    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX>), ldsBytes);
-    staged_apply<STENCIL, PER, KMAX><<<grid, kBlock, ldsBytes, stream>>>(a);
+    constexpr size_t buf = (size_t)(KMAX * kBlock * 4 + 4) * sizeof(float);
+    const int nbuf = tuning("STAGE_NBUF", 2);
+    if constexpr (3 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
+        if (nbuf == 3) { launch_staged_n<STENCIL, PER, KMAX, 3>(a, grid, stream); return; }
+    }
+    if constexpr (4 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
+        if (nbuf == 4) { launch_staged_n<STENCIL, PER, KMAX, 4>(a, grid, stream); return; }
+    }
+    if constexpr (6 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024 && (4 * KMAX + 5 * PER) < 64) {
+        if (nbuf == 6) { launch_staged_n<STENCIL, PER, KMAX, 6>(a, grid, stream); return; }
+    }
+    launch_staged_n<STENCIL, PER, KMAX, 2>(a, grid, stream);
 }
 
 template <int STENCIL>

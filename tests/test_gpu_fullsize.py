@@ -125,3 +125,29 @@ def test_c5_wind_pair_rotation_and_creepfill(fa):
     ok = ~np.isnan(ru[0])
     assert cases.same(gu[0][ok], ru[0][ok])               # defined cells are untouched by the fill
     np.testing.assert_allclose(np.hypot(gu[0][ok], gv[0][ok]), np.hypot(iu[0][ok], iv[0][ok]), rtol=1e-5)  # length kept
+
+
+def test_host_calls_with_slices_beyond_the_staging_buffers(fa):
+    """A slice larger than one pinned staging slot (64 MB) leaves the streamed path and is copied whole; smaller ones stream in
+    several chunks through the ring of three slots.  Both against the oracle, both orders of magnitude of nz."""
+    rng = np.random.default_rng(7)
+    inX, inY, outX, outY = 4200, 4100, 300, 200          # 68.9 MB per source slice
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=9)
+    f = rng.normal(0, 1, (2, inY, inX)).astype(np.float32)
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY)
+    got = plan.apply_host(f)
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY, nthreads=16)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    s16 = (f * 1000).astype(np.int16)
+    got16 = fa.regrid_slice_typed_host(plan, s16, -32767.0)
+    w16 = oracle.interpolation_array2data(oracle.interpolate_values(oracle.BILINEAR, px, py, oracle.data2interpolation_array(s16, -32767.0),
+                                                                    inX, inY, outX, outY, nthreads=16), oracle.CDM_SHORT, -32767.0)
+    assert np.array_equal(got16, w16.reshape(got16.shape))
+    # 11 slices of 22 MB: chunks of two slices, six chunks through three slots
+    inX, inY = 2400, 2300
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=10)
+    f = rng.normal(0, 1, (11, inY, inX)).astype(np.float32)
+    plan = fa.RegridPlan(oracle.BICUBIC, px, py, inX, inY, outX, outY)
+    got = plan.apply_host(f)
+    want = oracle.interpolate_values(oracle.BICUBIC, px, py, f, inX, inY, outX, outY, nthreads=16)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)

@@ -441,7 +441,7 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
     plan.info.undefinedCells = (size_t)h.undefined;
     plan.info.borderCells = (size_t)h.border;
     // bilinear: also the LDS-staged form (staged.hip); plans whose tiles do not fit keep the gather kernel only
-    if ((plan.kind == PlanKind::Bilinear || plan.kind == PlanKind::Bicubic) && tuning("STAGED", 1) != 0 &&
+    if (tuning("STAGED", 1) != 0 && (plan.kind != PlanKind::Nearest || tuning("STAGED_NEAREST", 1) != 0) &&
         build_staged_plan(plan, d_px, d_py, stream)) {
         const auto& s = plan.staged;  // the staged kernel reads LDS offsets instead of pos, plus the tile tables
         plan.info.planBytes = plan.info.planBytes - plan.pos.bytes() + s.ldsA.bytes() + s.ldsB.bytes() + s.tileHdr.bytes() +

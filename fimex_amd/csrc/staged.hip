@@ -46,13 +46,18 @@ struct CellNeed {
     int64_t xa, xb, ya, yb;
 };
 
-// STENCIL 2: bilinear incl. its border branches (src/interpolation.c:883-954); 4: bicubic (:970-976)
+// STENCIL 1: nearest (src/interpolation.c:862-879); 2: bilinear incl. its border branches (:883-954); 4: bicubic (:970-976)
 template <int STENCIL>
 __device__ CellNeed classify(double x, double y, int64_t ix, int64_t iy)
 {
     CellNeed c{};
     c.valid = false;
     if (!usable(x, y)) return c;
+    if (STENCIL == 1) {  // nearest: lround half away from zero (src/interpolation.c:864-868)
+        const int64_t rx = (int64_t)round(x), ry = (int64_t)round(y);
+        if (rx >= 0 && rx < ix && ry >= 0 && ry < iy) { c.valid = true; c.xa = c.xb = rx; c.ya = c.yb = ry; }
+        return c;
+    }
     const int64_t x0 = (int64_t)floor(x), y0 = (int64_t)floor(y);
     if (STENCIL == 4) {
         if ((1 <= x0) && (x0 + 2 < ix) && (1 <= y0) && (y0 + 2 < iy)) {
@@ -302,11 +307,11 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
             cellOff[k] = cell * 4u;
             pa = a.ldsA[cell];
             if (STENCIL == 4) { pb = a.ldsB[cell]; fx = a.xfd[cell]; fy = a.yfd[cell]; }
-            else { xf[k] = a.xf[cell]; yf[k] = a.yf[cell]; }
+            else if (STENCIL == 2) { xf[k] = a.xf[cell]; yf[k] = a.yf[cell]; }
         }
         undef[k] = pa == kInvalidPos;  // undefined cells read LDS offset 0 and discard it
         row[k][0] = undef[k] ? 0u : (pa & 0xFFFFu) * 4u;
-        row[k][1] = undef[k] ? 0u : (pa >> 16) * 4u;
+        if (STENCIL >= 2) row[k][STENCIL >= 2 ? 1 : 0] = undef[k] ? 0u : (pa >> 16) * 4u;
         if (STENCIL == 4) {
             row[k][2] = undef[k] ? 0u : (pb & 0xFFFFu) * 4u;
             row[k][3] = undef[k] ? 0u : (pb >> 16) * 4u;
@@ -367,7 +372,14 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
         const float* cur = smem + slot * kBufFloats;
         const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, (a.ablate & 2) ? 0u : outBytes);
         const char* curb = reinterpret_cast<const char*>(cur);
-        if constexpr (STENCIL == 2) {
+        if constexpr (STENCIL == 1) {
+            float v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);  // :869-876
+        } else if constexpr (STENCIL == 2) {
             float s00[PER], s01[PER], s10[PER], s11[PER];
 #pragma unroll
             for (int k = 0; k < PER; ++k) {  // all stencil reads first: 2 x ds_read2_b32 per output, no waits in between
@@ -503,6 +515,13 @@ bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const do
             if (forcedK && (uint32_t)forcedK != sh[1]) continue;
             if (try_build_staged<2>(plan, d_px, d_py, stream, tw, sh[0], sh[1])) return true;
         }
+    } else if (plan.kind == PlanKind::Nearest) {
+        const uint32_t shapes[3][2] = {{4, 4}, {4, 6}, {8, 8}};
+        for (const auto& sh : shapes) {
+            if (forcedPer && (uint32_t)forcedPer != sh[0]) continue;
+            if (forcedK && (uint32_t)forcedK != sh[1]) continue;
+            if (try_build_staged<1>(plan, d_px, d_py, stream, tw, sh[0], sh[1])) return true;
+        }
     } else if (plan.kind == PlanKind::Bicubic) {
         const uint32_t shapes[4][2] = {{2, 3}, {2, 4}, {4, 6}, {4, 8}};
         for (const auto& sh : shapes) {
@@ -554,7 +573,14 @@ void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, s
     FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
     const dim3 grid(gridX, (uint32_t)chunks, 1);
     const uint32_t key = s.per * 100 + s.kmax;
-    if (plan.kind == PlanKind::Bilinear) {
+    if (plan.kind == PlanKind::Nearest) {
+        switch (key) {
+        case 404: launch_staged<1, 4, 4>(a, grid, stream); break;
+        case 406: launch_staged<1, 4, 6>(a, grid, stream); break;
+        case 808: launch_staged<1, 8, 8>(a, grid, stream); break;
+        default: throw Error("staged nearest: unexpected tile shape");
+        }
+    } else if (plan.kind == PlanKind::Bilinear) {
         switch (key) {
         case 404: launch_staged<2, 4, 4>(a, grid, stream); break;
         case 406: launch_staged<2, 4, 6>(a, grid, stream); break;

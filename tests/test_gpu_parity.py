@@ -61,14 +61,14 @@ def test_backward_ragged_z_counts(fa, method, nz):
     assert cases.same(got, want), cases.describe_mismatch(got, want)
 
 
-@pytest.mark.parametrize("method", [oracle.BILINEAR, oracle.BICUBIC])
+@pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
 @pytest.mark.parametrize("shape", [(400, 300, 200, 200, 10), (1000, 700, 333, 257, 7), (128, 96, 640, 480, 3), (64, 2000, 50, 300, 5)])
 @pytest.mark.parametrize("knobs", [{"STAGED": "0"}, {"STAGED": "1"}, {"STAGED": "1", "STAGE_TW": "128"},
                                    {"STAGED": "1", "STAGE_TW": "32", "STAGE_ZPB": "3"},
                                    {"STAGED": "1", "STAGE_TW": "256", "STAGE_ZPB": "1", "XCD": "1"},
                                    {"STAGED": "1", "XCD": "3", "STAGED_MIN_NZ": "1"}])
 def test_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, method, shape, knobs):
-    """Both kernels of bilinear and bicubic (per-lane gather, LDS-staged tiles) on source widths that allow staging
+    """Both kernels of nearest, bilinear and bicubic (per-lane gather, LDS-staged tiles) on source widths that allow staging
     (inX % 4 == 0): shrinking (several source cells per target cell), magnifying, and strongly anisotropic geometries,
     different tile shapes, z chunkings and tile orders."""
     inX, inY, outX, outY, nz = shape
@@ -89,9 +89,12 @@ def test_bilinear_scattered_positions_fall_back_to_gather(fa):
     px = rng.uniform(-3, inX + 2, outX * outY)
     py = rng.uniform(-3, inY + 2, outX * outY)
     f = cases.field(nz, inY, inX, seed=8)
-    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
-    got = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY).apply_host(f)
-    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    for method in (oracle.BILINEAR, oracle.NEAREST):
+        want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
+        plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+        assert plan.info()["stagedCells"] == 0
+        got = plan.apply_host(f)
+        assert cases.same(got, want), cases.describe_mismatch(got, want)
 
 
 def test_backward_empty_and_query(fa):

@@ -206,7 +206,7 @@ struct StagedArgs {
     size_t inLayer;
     uint32_t nOut;
     uint32_t nz, zPerBlock;
-    uint32_t tilesPerXcd, xcdRemap;
+    uint32_t tilesPerXcd, xcdRemap, storeAux, loadAux;
     uint32_t ablate;  // diagnostics only (FIMEX_AMD_ABLATE): 1 = no source loads, 2 = no output stores
 };
 
@@ -218,13 +218,19 @@ __device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
 
 // One LDS-DMA wave instruction: 64 lanes x 16 bytes from per-lane buffer offsets to ldsBase + lane * 16.
 // (The builtin exists only in the device pass; the host pass of hipcc parses kernel bodies too.)
-__device__ __forceinline__ void dma16(rsrc_t rs, float* ldsBase, uint32_t voff)
+__device__ __forceinline__ void dma16(rsrc_t rs, float* ldsBase, uint32_t voff, uint32_t aux = 0)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using lds_ptr = __attribute__((address_space(3))) void*;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 0);
+    switch (aux) {  // cache policy, wave-uniform (tuning knob LOAD_AUX; the default policy measured best)
+    case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 1); break;
+    case 16: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 16); break;
+    case 17: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 17); break;
+    case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 2); break;
+    default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 0); break;
+    }
 #else
-    (void)rs; (void)ldsBase; (void)voff;
+    (void)rs; (void)ldsBase; (void)voff; (void)aux;
 #endif
 }
 
@@ -355,7 +361,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     auto dma = [&](float* dst, uint32_t z) {
         const rsrc_t rs = make_rsrc(a.in + (size_t)z * a.inLayer, (a.ablate & 1) ? 0u : inBytes);
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j]);
+        for (int j = 0; j < KMAX; ++j) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
     };
 
     // prologue: NBUF - 1 slices in flight, the first one landed
@@ -397,7 +403,16 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                 const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
                 float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
                 r = undef[k] ? undefined_f() : r;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+                switch (a.storeAux) {  // cache policy of the result stores (wave-uniform): 2 = non-temporal is the default
+                case 0: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 0); break;
+                case 1: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 1); break;
+                case 3: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 3); break;
+                case 16: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 16); break;
+                case 17: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 17); break;
+                case 18: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 18); break;
+                case 19: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 19); break;
+                default: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2); break;
+                }
             }
         } else {
 #pragma unroll
@@ -563,6 +578,8 @@ void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, s
     a.zPerBlock = zpb;
     a.xcdRemap = (uint32_t)tuning("XCD", 0);
     a.ablate = (uint32_t)tuning("ABLATE", 0);
+    a.storeAux = (uint32_t)tuning("STORE_AUX", 2);
+    a.loadAux = (uint32_t)tuning("LOAD_AUX", 0);
     a.tilesPerXcd = (uint32_t)ceil_div(s.nTiles, kXcds);
     uint32_t gridX = a.tilesPerXcd * kXcds;
     if (a.xcdRemap >= 2) {  // whole stripes per XCD

@@ -151,3 +151,36 @@ def test_host_calls_with_slices_beyond_the_staging_buffers(fa):
     got = plan.apply_host(f)
     want = oracle.interpolate_values(oracle.BICUBIC, px, py, f, inX, inY, outX, outY, nthreads=16)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+@pytest.mark.parametrize("method,tol", [(oracle.BILINEAR, 2e-6), (oracle.BICUBIC, 4e-6), (oracle.NEAREST, 0.0)])
+def test_c2_linearity_at_full_size(fa, c2, method, tol):
+    """Size-independent property on the whole 2000x2000 target: regrid(a f + b g) = a regrid(f) + b regrid(g) up to float
+    rounding (exactly for nearest, which only copies), with the same cells undefined."""
+    wl, px, py, f = c2
+    rng = np.random.default_rng(5)
+    g = rng.normal(0, 3, f[:2].shape).astype(np.float32)
+    a, b = np.float32(0.5), np.float32(2.0)   # powers of two: the combination itself is exact
+    plan = fa.RegridPlan(method, px, py, wl.inX, wl.inY, wl.outX, wl.outY)
+    lhs = plan.apply_host(a * f[:2] + b * g)
+    rf, rg = plan.apply_host(f[:2]), plan.apply_host(g)
+    rhs = a * rf + b * rg
+    assert np.array_equal(np.isnan(lhs), np.isnan(rhs))
+    ok = ~np.isnan(lhs)
+    scale = np.abs(a * rf[ok]) + np.abs(b * rg[ok]) + 1e-30
+    assert np.max(np.abs(lhs[ok] - rhs[ok]) / scale) <= tol
+
+
+def test_fills_are_idempotent_at_full_size(fa):
+    """A filled slice has nothing left to fill: the second call returns its input bit for bit and reports no undefined cell."""
+    n = 3000
+    f = cases.holes(2, n, n, seed=12, frac=0.2)
+    once, n1 = fa.creepfill2d_host(f, 5, 2)
+    twice, n2 = fa.creepfill2d_host(once, 5, 2)
+    assert not np.isnan(once).any() and all(k > 0 for k in n1) and n2 == [0, 0]
+    assert np.array_equal(once.view(np.uint32), twice.view(np.uint32))
+    keep = ~np.isnan(f)
+    assert np.array_equal(once[keep].view(np.uint32), f[keep].view(np.uint32))  # defined cells are never touched
+    filled, m1 = fa.fill2d_host(f, 4.0, 1.6, 30)
+    again, m2 = fa.fill2d_host(filled, 4.0, 1.6, 30)
+    assert m2 == [0, 0] and np.array_equal(filled.view(np.uint32), again.view(np.uint32))

@@ -10,7 +10,6 @@
 #include <vector>
 
 #include "CachedInterpolation.h"
-#include "Projection.h"
 
 namespace FimexAmd {
 

@@ -1,4 +1,7 @@
-// Map projections for plan building, on spheres, from their published closed forms (Snyder, USGS PP 1395).
+// Map projections on spheres from their published closed forms (Snyder, USGS PP 1395) -- the HOST copy.
+// Plan building itself runs on the device (fimex_amd/csrc/projection.hip behind fimex_amd_project_axes_* etc., which
+// CDMInterpolator.cc calls); this copy serves host_cli's --project / --matrix modes, the GPU-less cross-check of the same
+// formulas in tests/test_host_projection.py.
 //
 // The reference obtains these from the third-party library PROJ.4 through pj_init_plus / pj_transform
 // (call sites src/interpolation.c:355,396,644,700,773,1185,1233).  PROJ.4 is not part of the reference tree and

@@ -23,6 +23,7 @@
 #include <sstream>
 
 #include "CDMInterpolator.h"
+#include "Projection.h"
 
 using namespace FimexAmd;
 

@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
         for (int j = 0; j < KMAX; ++j) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
     };
 
-    // prologue: NBUF - 1 slices in flight, the first one landed
+    // prologue: NBUF - 1 slices in flight, the first one landed (NBUF == 1: no prefetch, the slice is fetched, then used)
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
         if (z0 + i < z1) dma(smem + i * kBufFloats, z0 + i);
@@ -374,7 +374,14 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     uint32_t slot = 0;
     for (uint32_t z = z0; z < z1; ++z) {
         const bool more = z + (NBUF - 1) < z1;
-        if (more) dma(smem + ((slot + NBUF - 1) % NBUF) * kBufFloats, z + (NBUF - 1));  // into the buffer slice z - 1 has left
+        if (NBUF == 1) {
+            dma(smem, z);
+            wait_vmcnt<0>();  // results return in issue order: the DMA is the most recent, everything before it has to land too
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else if (more) {
+            dma(smem + ((slot + NBUF - 1) % NBUF) * kBufFloats, z + (NBUF - 1));  // into the buffer slice z - 1 has left
+        }
         const float* cur = smem + slot * kBufFloats;
         const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, (a.ablate & 2) ? 0u : outBytes);
         const char* curb = reinterpret_cast<const char*>(cur);
@@ -439,7 +446,8 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
         // Slice z + 1 must have landed.  Results come back in issue order: behind its DMA are the DMAs of slices
         // z + 2 .. z + NBUF - 1 and the stores of NBUF - 1 slices, which may all stay in flight.  At the end of the run
         // (no new DMA issued) only this slice's stores may.
-        if (more) wait_vmcnt<(NBUF - 2) * KMAX + (NBUF - 1) * PER>();
+        if (NBUF == 1) { /* the buffer is rewritten after the barrier below */ }
+        else if (more) wait_vmcnt<(NBUF >= 2 ? (NBUF - 2) * KMAX + (NBUF - 1) * PER : 0)>();
         else wait_vmcnt<PER>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -461,6 +469,7 @@ void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
     constexpr size_t buf = (size_t)(KMAX * kBlock * 4 + 4) * sizeof(float);
     const int nbuf = tuning("STAGE_NBUF", 2);
+    if (nbuf == 1) { launch_staged_n<STENCIL, PER, KMAX, 1>(a, grid, stream); return; }
     if constexpr (3 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
         if (nbuf == 3) { launch_staged_n<STENCIL, PER, KMAX, 3>(a, grid, stream); return; }
     }

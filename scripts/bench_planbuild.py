@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Plan build of the benchmark geometry (4 M target cells): projection + axis positions + plan tables + rotation matrix,
-device resident, against the numpy restatement of the same chain on one host core."""
+device resident."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,15 +33,5 @@ for _ in range(4):
     fa.get_vector_reproject_matrix_device(wl.source_proj, wl.target_proj, np.degrees(tx), np.degrees(ty), fa.LONGITUDE, fa.LATITUDE, m.data_ptr(), st)
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 print(json.dumps({"step": "vector reproject matrix", "cells": n, "ms": min(ts[1:]) * 1e3}), flush=True)
-# one host core, numpy, same closed forms
-sys.path.insert(0, os.path.join(ROOT))
-import oracle
-from oracle import proj_oracle as po
-t0 = time.perf_counter()
-px, py = po.project_axes(wl.target_proj, wl.source_proj, tx, ty)
-t1 = time.perf_counter()
-px = oracle.points2position(px, ax, oracle.LONGITUDE); py = oracle.points2position(py, ay, oracle.LATITUDE)
-t2 = time.perf_counter()
-print(json.dumps({"step": "cpu restatement (numpy projection, C axis positions), 1 core", "project_ms": (t1 - t0) * 1e3, "points2position_ms": (t2 - t1) * 1e3}), flush=True)
-got = d.cpu().numpy()
-print(json.dumps({"max_abs_position_diff_vs_cpu": float(max(np.nanmax(np.abs(got[:n] - px)), np.nanmax(np.abs(got[n:] - py))))}), flush=True)
+# The CPU side of this comparison (numpy projection + C axis positions on one core: 346 + 188 ms, positions equal to 5e-12) was
+# measured once through tests' oracle and is recorded in profiles/r01_planbuild.jsonl; scripts do not touch oracle/.

@@ -79,6 +79,7 @@ SYMBOLS = {
     "fimex_amd_points2position_host": (ctypes.c_int, [_D, _Z, _D, ctypes.c_int, ctypes.c_int]),
     "fimex_amd_data2interpolation_device": (ctypes.c_int, [_V, ctypes.c_int, _Z, ctypes.c_double, _V, _V]),
     "fimex_amd_interpolation2data_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, ctypes.c_double, _V, _V]),
+    "fimex_amd_regrid_apply_typed_device": (ctypes.c_int, [_V, _V, ctypes.c_int, _Z, ctypes.c_double, _V, _V]),
     "fimex_amd_data2interpolation_host": (ctypes.c_int, [_V, ctypes.c_int, _Z, ctypes.c_double, _F]),
     "fimex_amd_interpolation2data_host": (ctypes.c_int, [_F, _Z, ctypes.c_int, ctypes.c_double, _V]),
     "fimex_amd_regrid_slice_typed_host": (ctypes.c_int, [_V, _V, ctypes.c_int, _Z, ctypes.c_double, ctypes.POINTER(Process2d), _Z,
@@ -296,6 +297,10 @@ def cdm_type_of(dtype):
         if np.dtype(dt) == np.dtype(dtype):
             return code
     raise TypeError("no CDMDataType for %s" % dtype)
+
+
+def regrid_apply_typed_device(plan, d_in, cdmType, nz, badValue, d_out, stream=0):
+    _check(load().fimex_amd_regrid_apply_typed_device(plan._h, d_in, cdmType, nz, badValue, d_out, stream))
 
 
 def data2interpolation_device(d_in, cdmType, n, badValue, d_out, stream=0):

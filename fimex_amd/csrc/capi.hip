@@ -457,6 +457,7 @@ void regrid_slice(const fimex_amd_regrid_plan* plan, bool typed, const void* inD
         const bool convert = typed && dataType != FIMEX_AMD_CDM_FLOAT;
         if (pipelined_slices(plan->device, inData, inLayer * elem, outData, outLayer * elem, convert ? inLayer : 0, typed ? outLayer : 0, nz,
                              [&](const void* dIn, void* dOut, float* fIn, float* fOut, size_t nzc, hipStream_t st) {
+                                 if (typed && launch_typed_apply(*plan, dIn, dataType, nzc, badValue, dOut, st)) return;
                                  const float* src = static_cast<const float*>(dIn);
                                  if (convert) {
                                      launch_data2interpolation(dIn, dataType, nzc * inLayer, badValue, fIn, st);
@@ -558,6 +559,26 @@ int fimex_amd_data2interpolation_device(const void* d_in, int cdmType, size_t n,
         FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
         (void)current_device_checked();
         launch_data2interpolation(d_in, cdmType, n, badValue, d_out, as_stream(stream));
+    });
+}
+
+int fimex_amd_regrid_apply_typed_device(const fimex_amd_regrid_plan* plan, const void* d_in, int cdmType, size_t nz, double badValue,
+                                        void* d_out, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        (void)cdm_type_size(cdmType);
+        if (nz == 0) return;
+        FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
+        ScopedDevice dev(plan->device);
+        hipStream_t st = as_stream(stream);
+        if (launch_typed_apply(*plan, d_in, cdmType, nz, badValue, d_out, st)) return;
+        const size_t inLayer = plan->inX * plan->inY, outLayer = plan->outX * plan->outY;
+        DeviceArray<float> fIn(nz * inLayer), fOut(nz * outLayer);
+        launch_data2interpolation(d_in, cdmType, nz * inLayer, badValue, fIn.get(), st);
+        apply_device(*plan, fIn.get(), nz, fOut.get(), st);
+        launch_interpolation2data(fOut.get(), nz * outLayer, cdmType, badValue, d_out, st);
+        FA_HIP(hipStreamSynchronize(st));  // the temporaries are released on return
     });
 }
 

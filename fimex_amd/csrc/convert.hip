@@ -3,6 +3,7 @@
 // Replaces mifi_bad2nanf / mifi_nanf2bad (src/interpolation.c:1775-1793) and
 // mifi_points2position (src/interpolation.c:104-217).
 #include "plan.hpp"
+#include "typed_convert.hpp"
 
 #include <cmath>
 #include <string>
@@ -85,13 +86,6 @@ void launch_replace(float* d, size_t n, float bad, hipStream_t stream)
 template <typename T>
 using Vec4 = T __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__device__ __forceinline__ float as_float_nan(T v, float bad, bool hasBad)
-{
-    const float f = (float)v;
-    return (hasBad && f == bad) ? undefined_f() : f;  // interpolation.c:1778; a NaN fill value leaves the data alone (:1776)
-}
-
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(kBlock) to_float_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n, float bad, bool hasBad)
 {
@@ -109,25 +103,6 @@ __global__ void __launch_bounds__(kBlock) to_float_kernel(const T* __restrict__ 
     } else {
         for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = as_float_nan(in[i], bad, hasBad);
     }
-}
-
-// MetNoFimex::round(double) (include/fimex/Utils.h:72-75): lround, then long -> int.  Outside the range of long the
-// reference is unspecified; LONG_MIN (what glibc/x86-64 yields) is kept (DESIGN.md divergence D6).
-__device__ __forceinline__ int mifi_round(double num)
-{
-    const long long r = (fabs(num) < 9223372036854775808.0) ? llround(num) : (-9223372036854775807LL - 1);
-    return (int)r;
-}
-
-// float -> T is ScaleValue<float, T>(NaN, 1, 0, fill, 1, 0) (include/fimex/Utils.h:444-464): NaN -> fill, else
-// data_caster<T, double>(1.0 * v + 0.0): through mifi_round for integer T, a plain cast otherwise
-template <typename T>
-__device__ __forceinline__ T from_float_fill(float v, T fill)
-{
-    if (isnan(v)) return fill;
-    const double d = 1.0 * (double)v + 0.0;  // turns -0.0 into +0.0, as the reference does
-    if (std::is_integral<T>::value) return (T)mifi_round(d);
-    return (T)d;
 }
 
 template <typename T, bool VEC>

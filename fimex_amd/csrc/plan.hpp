@@ -104,6 +104,9 @@ size_t cdm_type_size(int cdmType);  // throws for types without a float form
 void launch_data2interpolation(const void* d_in, int cdmType, size_t n, double badValue, float* d_out, hipStream_t stream);
 void launch_interpolation2data(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, hipStream_t stream);
 
+bool launch_typed_apply(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                        hipStream_t stream);
+
 // projection.hip: pj_transform-level plan building on the device
 void launch_project_values(const char* projIn, const char* projOut, double* d_x, double* d_y, size_t n, hipStream_t stream);
 void launch_project_axes(const char* projIn, const char* projOut, const double* h_xAxis, const double* h_yAxis, size_t ix, size_t iy,

@@ -22,6 +22,9 @@
 // the same type and order as the reference, so results are bit-identical to the CPU path.
 #include "plan.hpp"
 
+#include <algorithm>
+#include "typed_convert.hpp"
+
 namespace fimex_amd {
 
 namespace {
@@ -399,6 +402,137 @@ ApplyArgs make_args(const fimex_amd_regrid_plan& plan, const float* d_in, size_t
     return a;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same three stencils on a variable's STORED type: elements of T are read as they lie in the file
+// (packed shorts, bytes), become float with the fill value as NaN in the register (data2InterpolationArray), and the
+// result goes back to T with NaN as the fill value (interpolationArray2Data) -- per element the operations of the
+// float kernels bracketed by those of convert.hip, so the bytes moved are sizeof(T) instead of 4 + the two passes.
+struct TypedArgs {
+    ApplyArgs g;          // geometry; g.in / g.out unused
+    const void* in;
+    void* out;
+    float bad;            // the fill value narrowed to float (mifi_bad2nanf's parameter)
+    int hasBad;
+    double fillOut;       // the fill value as interpolationArray2Data receives it
+};
+
+template <typename T>
+__device__ __forceinline__ T ld_raw(rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    if (sizeof(T) == 1) return (T)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+    if (sizeof(T) == 2) return (T)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    return (T)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+template <typename T>
+__device__ __forceinline__ void st_raw(rsrc_t r, uint32_t voff, uint32_t soff, T v)
+{
+    if (sizeof(T) == 1) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff, soff, 2);
+    else if (sizeof(T) == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, r, voff, soff, 2);
+}
+
+// METHOD 0 nearest, 1 bilinear, 2 bicubic
+template <int METHOD, typename T>
+__global__ void __launch_bounds__(kBlock) typed_apply(TypedArgs t, const uint32_t* __restrict__ pos, const float* __restrict__ xfrac,
+                                                      const float* __restrict__ yfrac, const double* __restrict__ xfd,
+                                                      const double* __restrict__ yfd)
+{
+    const ApplyArgs& a = t.g;
+    uint32_t cell;
+    if (!tile_cell(a, cell)) return;
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    constexpr uint32_t E = sizeof(T);
+    const uint32_t inBytes = (uint32_t)a.inLayer * E, outBytes = a.nOut * E;
+    const char* src = static_cast<const char*>(t.in) + (size_t)z0 * inBytes;
+    char* o = static_cast<char*>(t.out) + (size_t)z0 * outBytes;
+    const uint32_t cb = cell * E;
+    const T fill = static_cast<T>(t.fillOut);  // ScaleValue's newFill_ (Utils.h:456)
+    const bool hasBad = t.hasBad != 0;
+    auto rsrc_in = [&](const char* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, inBytes, 0x00020000); };
+    auto rsrc_out = [&](char* p) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, outBytes, 0x00020000); };
+    auto get = [&](rsrc_t rs, uint32_t off) { return as_float_nan(ld_raw<T>(rs, off, 0), t.bad, hasBad); };
+    const uint32_t p = pos[cell];
+    if (p == kInvalidPos) {
+        for (uint32_t z = z0; z < z1; ++z, o += outBytes) st_raw<T>(rsrc_out(o), cb, 0, fill);  // undefined -> NaN -> fill value
+        return;
+    }
+    const uint32_t pb = p * E;
+    constexpr int ZC = 8;  // slices whose loads are in flight together (one descriptor spans them: ZC * slice bytes < 4 GiB, checked on the host)
+    auto rsrc_in_n = [&](const char* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(q), 0, inBytes * ZC, 0x00020000); };
+    auto rsrc_out_n = [&](char* q) { return __builtin_amdgcn_make_buffer_rsrc(q, 0, outBytes * ZC, 0x00020000); };
+    auto getk = [&](rsrc_t rs, uint32_t off, int k) { return as_float_nan(ld_raw<T>(rs, off, inBytes * k), t.bad, hasBad); };
+    if (METHOD == 0) {
+        uint32_t z = z0;
+        for (; z + ZC <= z1; z += ZC, src += (size_t)ZC * inBytes, o += (size_t)ZC * outBytes) {
+            const rsrc_t rs = rsrc_in_n(src), ro = rsrc_out_n(o);
+            float v[ZC];
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) v[k] = getk(rs, pb, k);
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) st_raw<T>(ro, cb, outBytes * k, from_float_fill<T>(v[k], fill));
+        }
+        for (; z < z1; ++z, src += inBytes, o += outBytes)
+            st_raw<T>(rsrc_out(o), cb, 0, from_float_fill<T>(get(rsrc_in(src), pb), fill));
+    } else if (METHOD == 1) {
+        const float xf = xfrac[cell], yf = yfrac[cell];
+        const bool nnx = (__float_as_uint(xf) >> 31) != 0, nny = (__float_as_uint(yf) >> 31) != 0;
+        const uint32_t pb1 = pb + a.ix * E;
+        uint32_t z = z0;
+        if (!(nnx || nny)) {
+            for (; z + ZC <= z1; z += ZC, src += (size_t)ZC * inBytes, o += (size_t)ZC * outBytes) {
+                const rsrc_t rs = rsrc_in_n(src), ro = rsrc_out_n(o);
+                float s00[ZC], s01[ZC], s10[ZC], s11[ZC];
+#pragma unroll
+                for (int k = 0; k < ZC; ++k) {
+                    s00[k] = getk(rs, pb, k);
+                    s01[k] = getk(rs, pb + E, k);
+                    s10[k] = getk(rs, pb1, k);
+                    s11[k] = getk(rs, pb1 + E, k);
+                }
+#pragma unroll
+                for (int k = 0; k < ZC; ++k)
+                    st_raw<T>(ro, cb, outBytes * k, from_float_fill<T>(bilinear_point(s00[k], s01[k], s10[k], s11[k], xf, yf), fill));
+            }
+        }
+        for (; z < z1; ++z, src += inBytes, o += outBytes) {
+            const rsrc_t rs = rsrc_in(src);
+            const float s00 = get(rs, pb);
+            float r;
+            if (!(nnx || nny)) r = bilinear_point(s00, get(rs, pb + E), get(rs, pb1), get(rs, pb1 + E), xf, yf);
+            else if (nnx && nny) r = s00;                                   // :939-942
+            else if (nny) r = (1.f - xf) * s00 + xf * get(rs, pb + E);      // :911
+            else r = (1 - yf) * s00 + (yf * get(rs, pb1));                  // :931
+            st_raw<T>(rsrc_out(o), cb, 0, from_float_fill<T>(r, fill));
+        }
+    } else {
+        double XM[4], MY[4];
+        cubic_weights(xfd[cell], XM);
+        cubic_weights(yfd[cell], MY);
+        for (uint32_t z = z0; z < z1; ++z, src += inBytes, o += outBytes) {
+            const rsrc_t rs = rsrc_in(src);
+            float f[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[i][j] = get(rs, pb + (i * a.ix + j) * E);
+            st_raw<T>(rsrc_out(o), cb, 0, from_float_fill<T>(bicubic_point(f, XM, MY), fill));
+        }
+    }
+}
+
+template <typename T>
+void launch_typed_t(const fimex_amd_regrid_plan& plan, const TypedArgs& t, dim3 grid, hipStream_t stream)
+{
+    switch (plan.kind) {
+    case PlanKind::Nearest: typed_apply<0, T><<<grid, kBlock, 0, stream>>>(t, plan.pos.get(), nullptr, nullptr, nullptr, nullptr); break;
+    case PlanKind::Bilinear: typed_apply<1, T><<<grid, kBlock, 0, stream>>>(t, plan.pos.get(), plan.xf.get(), plan.yf.get(), nullptr, nullptr); break;
+    case PlanKind::Bicubic: typed_apply<2, T><<<grid, kBlock, 0, stream>>>(t, plan.pos.get(), nullptr, nullptr, plan.xfd.get(), plan.yfd.get()); break;
+    default: throw Error("typed apply: not a backward plan");
+    }
+    FA_HIP(hipGetLastError());
+}
+
 }  // namespace
 
 void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
@@ -500,6 +634,37 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
         throw Error("launch_backward_apply: not a backward plan");
     }
     FA_HIP(hipGetLastError());
+}
+
+// Fused stored-type apply for 1- and 2-byte integer types and int32 (backward plans); returns false for everything else
+// (the caller then runs the three-pass sequence: to float, regrid, from float).
+bool launch_typed_apply(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                        hipStream_t stream)
+{
+    // bicubic: the LDS-staged float kernel between two conversion passes beats a 16-load gather on the stored type
+    if (plan.kind == PlanKind::Forward || (plan.kind == PlanKind::Bicubic && tuning("TYPED_FUSED", 1) < 2) || tuning("TYPED_FUSED", 1) == 0) return false;
+    if (!(cdmType == FIMEX_AMD_CDM_CHAR || cdmType == FIMEX_AMD_CDM_UCHAR || cdmType == FIMEX_AMD_CDM_SHORT ||
+          cdmType == FIMEX_AMD_CDM_USHORT || cdmType == FIMEX_AMD_CDM_INT))
+        return false;
+    if (nz == 0) return true;
+    FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
+    if (8 * 4 * std::max(plan.inX * plan.inY, plan.outX * plan.outY) > 0xFFFFFFFFull) return false;  // 8 slices behind one descriptor
+    TypedArgs t{};
+    dim3 grid;
+    t.g = make_args(plan, nullptr, nz, nullptr, grid);
+    t.in = d_in;
+    t.out = d_out;
+    t.bad = (float)badValue;
+    t.hasBad = !(t.bad != t.bad);
+    t.fillOut = badValue;
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: launch_typed_t<signed char>(plan, t, grid, stream); break;
+    case FIMEX_AMD_CDM_UCHAR: launch_typed_t<unsigned char>(plan, t, grid, stream); break;
+    case FIMEX_AMD_CDM_SHORT: launch_typed_t<short>(plan, t, grid, stream); break;
+    case FIMEX_AMD_CDM_USHORT: launch_typed_t<unsigned short>(plan, t, grid, stream); break;
+    default: launch_typed_t<int>(plan, t, grid, stream); break;
+    }
+    return true;
 }
 
 }  // namespace fimex_amd

@@ -237,6 +237,13 @@ int fimex_amd_data2interpolation_device(const void* d_in, int cdmType, size_t n,
  *  DataImpl<float>::convertDataType(MIFI_UNDEFINED_F, 1, 0, cdmType, badValue, 1, 0) does (NaN -> fill value,
  *  integers rounded through MetNoFimex::round), in one pass. */
 int fimex_amd_interpolation2data_device(const float* d_in, size_t n, int cdmType, double badValue, void* d_out, void* stream);
+/** interpolateValues on device-resident slices of a variable's stored type: d_in [nz][inY][inX] elements of cdmType ->
+ *  d_out [nz][outY][outX] elements of the same type, i.e. data2InterpolationArray, the regrid and interpolationArray2Data
+ *  of src/CDMInterpolator.cc:251-285 without pre/post-processes.  For backward plans on 1-, 2-byte and 32-bit integer
+ *  types this is ONE kernel that reads and writes the stored type (no float copy of the slices exists); other
+ *  combinations run the three passes on temporaries. */
+int fimex_amd_regrid_apply_typed_device(const fimex_amd_regrid_plan* plan, const void* d_in, int cdmType, size_t nz,
+                                        double badValue, void* d_out, void* stream);
 /** The same two conversions on host buffers (copied to the GPU and back), for callers that run their own 2-D processes
  *  on the float array in between. */
 int fimex_amd_data2interpolation_host(const void* in, int cdmType, size_t n, double badValue, float* out);

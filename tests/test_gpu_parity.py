@@ -628,3 +628,34 @@ def test_coord_search_rejects_bad_arguments(fa):
         fa.coord_kdtree_host(0.0, lon[0], lat[0], lon, lat)
     with pytest.raises(fa.FimexAmdError):
         fa.coord_nearest_host(lon[0], lat[0], np.full((8, 10), np.nan), lat)
+
+
+@pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
+@pytest.mark.parametrize("dt,bad", [(np.int16, -32767.0), (np.uint16, 65535.0), (np.int8, -127.0), (np.uint8, 255.0), (np.int32, -2147483647.0),
+                                    (np.float32, 9.96921e36), (np.float64, -1e30), (np.int64, -9.0e18)])
+def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, bad):
+    """fimex_amd_regrid_apply_typed_device: one kernel on the stored type for the small integer types, three passes for the
+    others, both against the oracle's three steps; the fused and the unfused GPU paths agree as well."""
+    import torch
+    inX, inY, outX, outY, nz = 96, 70, 150, 110, 19
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=12)
+    rng = np.random.default_rng(3)
+    if np.issubdtype(dt, np.integer):
+        info = np.iinfo(dt)
+        f = rng.integers(max(info.min, -30000) // 2, min(info.max, 30000) // 2 + 1, (nz, inY, inX)).astype(dt)
+    else:
+        f = rng.normal(0, 50, (nz, inY, inX)).astype(dt)
+    f.reshape(-1)[rng.choice(f.size, f.size // 25, replace=False)] = dt(bad)
+    code = oracle.cdm_type_of(dt)
+    want = oracle.interpolation_array2data(
+        oracle.interpolate_values(method, px, py, oracle.data2interpolation_array(f, bad), inX, inY, outX, outY), code, bad)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    t = torch.from_numpy(f.view(np.uint8)).cuda()
+    results = []
+    for fused in ("2", "1", "0"):  # 2: also bicubic through the stored-type kernel
+        monkeypatch.setenv("FIMEX_AMD_TYPED_FUSED", fused)
+        out = torch.zeros(nz * outY * outX * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+        fa.regrid_apply_typed_device(plan, t.data_ptr(), code, nz, bad, out.data_ptr())
+        torch.cuda.synchronize()
+        results.append(out.cpu().numpy().view(dt).reshape(want.shape))
+        assert np.array_equal(results[-1].view(np.uint8), want.view(np.uint8)), (fused, np.dtype(dt).name)

@@ -612,6 +612,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     if (b == 0) upCur = load_block(0, 0);
     else if (inGlobal) { wait_above(0); upCur = load_block(0, 0); }
     else upCur = take_above(0);
+    if ((b == 0 || inGlobal) && ((2 * kCh) & 63) == 0) {  // the event that would prefetch block 1 two chunks ahead is "chunk 0", which has none
+        if (inGlobal) wait_above((2 * kCh) >> 6);
+        upLd = load_block(0, (2 * kCh) >> 6);
+    }
     float downA = load_block(nrow + 1, 0), downB = downA, downLd = 0.f;  // current / next (landed) / in flight
     uint32_t downIssued = 0;
     bool downLdValid = false;
@@ -640,9 +644,11 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             }
             // row below: the last lane is at column x' - L
             if (downLdValid) { downB = downLd; downLdValid = false; }
-            if (xpc + 3 * kCh > L) {
-                const uint32_t k = (xpc + 3 * kCh - L) >> 6;
-                if (k > downIssued) { downLd = load_block(nrow + 1, k); downIssued = k; downLdValid = true; }
+            if (xpc + 2 * kCh > L && ((xpc + 2 * kCh - L) >> 6) > downIssued) {  // block j + 1 is requested two chunks before the last lane
+                // reaches it and lands in downB at the next event: after block j has moved on to downA, never skipping one
+                ++downIssued;
+                downLd = load_block(nrow + 1, downIssued);
+                downLdValid = true;
             }
             // row above: lane 0 is at column x'
             if ((xpc & 63) == 0 && (b == 0 || inGlobal)) upCur = upLd;  // from global, requested two chunks ago
@@ -1011,6 +1017,11 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
 // last repeat + 1 sweeps instead of a counter per cell.  Weights travel as floats (0, 1, setWeight: all exact).
 constexpr int kCreepWaves = 8;    // 8 waves x 256 registers: the creep step keeps more state than the 128 registers of a 16-wave workgroup hold
 constexpr int kCreepThreads = kCreepWaves * kWave;
+constexpr int kCreepCh = 32;                        // 128-byte row pieces per chunk: whole lines, one memory event per 32 columns
+constexpr int kCreepRingW = 2 * kCreepCh;
+constexpr int kCreepPitch = kCreepRingW + 1;
+constexpr int kCreepRowsPerIt = kWave / kCreepCh;
+constexpr int kCreepChunksPerWord = 32 / kCreepCh;
 constexpr int kHandWC = 128;  // hand-off window of the creep kernel: values and weight codes share the LDS left
 
 struct CreepV2Args {
@@ -1053,8 +1064,8 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     const uint32_t y = y0 + min(lane, L);
     const uint32_t C = nx - 2;
     const uint32_t xpEnd = C + L;
-    float* ringRow = ring + lane * kPitch;
-    const float* ringBelow = ring + min(lane + 1, (uint32_t)kWave - 1) * kPitch;
+    float* ringRow = ring + lane * kCreepPitch;
+    const float* ringBelow = ring + min(lane + 1, (uint32_t)kWave - 1) * kCreepPitch;
     const float left0 = f[(size_t)y * nx];
     const uint32_t* drow = maskD + (size_t)y * mws;
     const uint32_t* urow = uOld + (size_t)y * mws;
@@ -1065,50 +1076,50 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     // weight of border column 0 of my row: skewed column = lane
     const float wLeft0 = ((drow[lane >> 5] >> (lane & 31)) & 1u) ? swf : 0.f;
 
-    const uint32_t crow = lane / kCh, ccol = lane % kCh;
-    float stage[kCh];
+    const uint32_t crow = lane / kCreepCh, ccol = lane % kCreepCh;
+    float stage[kCreepCh];
     auto chunk_off = [&](uint32_t c, uint32_t it, bool store) -> uint32_t {
-        const uint32_t row = kRowsPerIt * it + crow;
-        const int64_t x = (int64_t)c * kCh + ccol - row;
+        const uint32_t row = kCreepRowsPerIt * it + crow;
+        const int64_t x = (int64_t)c * kCreepCh + ccol - row;
         const bool ok = row < nrow && (store ? (x >= 1 && x <= (int64_t)C) : (x >= 0 && x <= (int64_t)nx - 1));
         return ok ? (uint32_t)(((row + 1) * nx + x) * 4u) : kOob;
     };
     // interior chunks: lean addressing, see fill2d_band
-    auto interior = [&](uint32_t c) -> bool { return nrow == (uint32_t)kWave && c * kCh >= (uint32_t)kWave && c * kCh + kCh - 1 <= C; };
+    auto interior = [&](uint32_t c) -> bool { return nrow == (uint32_t)kWave && c * kCreepCh >= (uint32_t)kWave && c * kCreepCh + kCreepCh - 1 <= C; };
     const uint32_t voffLane = ((crow + 1) * nx + ccol - crow) * 4u;           // row crow, chunk 0, column ccol - crow
-    const uint32_t rowStep = (uint32_t)kRowsPerIt * (nx - 1) * 4u;            // next row group: kRowsPerIt rows down, as many columns back
-    float* ringLane = ring + crow * kPitch + ccol;
+    const uint32_t rowStep = (uint32_t)kCreepRowsPerIt * (nx - 1) * 4u;            // next row group: kCreepRowsPerIt rows down, as many columns back
+    float* ringLane = ring + crow * kCreepPitch + ccol;
     auto load_chunk = [&](uint32_t c) {
         if (interior(c)) {
-            const uint32_t s0 = c * kCh * 4u;
+            const uint32_t s0 = c * kCreepCh * 4u;
 #pragma unroll
-            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+            for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it)
                 stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voffLane, s0 + it * rowStep, 0));
             return;
         }
 #pragma unroll
-        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+        for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it)
             stage[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, chunk_off(c, it, false), 0, 0));
     };
     auto commit_chunk = [&](uint32_t c) {
-        float* dst = ringLane + ((c * kCh) & kCh);
+        float* dst = ringLane + ((c * kCreepCh) & kCreepCh);
 #pragma unroll
-        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) dst[kRowsPerIt * it * kPitch] = stage[it];
+        for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it) dst[kCreepRowsPerIt * it * kCreepPitch] = stage[it];
     };
     auto flush_chunk = [&](uint32_t c) {
-        float v[kCh];
-        const float* src = ringLane + ((c * kCh) & kCh);
+        float v[kCreepCh];
+        const float* src = ringLane + ((c * kCreepCh) & kCreepCh);
 #pragma unroll
-        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) v[it] = src[kRowsPerIt * it * kPitch];
+        for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it) v[it] = src[kCreepRowsPerIt * it * kCreepPitch];
         if (interior(c)) {
-            const uint32_t s0 = c * kCh * 4u;
+            const uint32_t s0 = c * kCreepCh * 4u;
 #pragma unroll
-            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+            for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
             return;
         }
 #pragma unroll
-        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
+        for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
     };
     auto load_block = [&](uint32_t rowInBuf, uint32_t k) {
@@ -1165,6 +1176,12 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     if (b == 0) { upCur = load_block(0, 0); upWCur = load_wblock(0, 0); }
     else if (inGlobal) { wait_above(0); upCur = load_block(0, 0); upWCur = load_wblock_above(0); }
     else take_above(0, upCur, upWCur);
+    if ((b == 0 || inGlobal) && ((2 * kCreepCh) & 63) == 0) {  // see fill2d_band
+        const uint32_t k = (2 * kCreepCh) >> 6;
+        if (inGlobal) wait_above(k);
+        upLd = load_block(0, k);
+        upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
+    }
     const uint32_t yBelow = y0 + nrow;
     float downA = load_block(nrow + 1, 0), downB = downA, downLd = 0.f;
     float downWA = load_wblock(yBelow, 0), downWB = downWA, downWLd = 0.f;
@@ -1179,23 +1196,23 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     float prevRes = 0.f, prevW = 0.f;
     float prevRight = ringRow[1];
 
-    const uint32_t nChunks = xpEnd / kCh + 1;
+    const uint32_t nChunks = xpEnd / kCreepCh + 1;
     for (uint32_t c = 0; c < nChunks; ++c) {
-        const uint32_t xpc = c * kCh;
+        const uint32_t xpc = c * kCreepCh;
         if (c > 0) {
             if (outGlobal) {
                 if (xpc > L) {  // stores of the previous event have landed: columns < 16 (c - 1) - L of the last row, values and U bits
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0 && xpc - kCh > L)
-                        lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L));
+                    if (lane == 0 && xpc - kCreepCh > L)
+                        lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCreepCh - L));
                 }
-                if (rowValid) nrowU[(c - 1) / kChunksPerWord] = un;  // the (partial) word of the chunk just finished
+                if (rowValid) nrowU[(c - 1) / kCreepChunksPerWord] = un;  // the (partial) word of the chunk just finished
             }
             // small loads first, the chunk prefetch last (see fill2d_band)
-            if ((c % kChunksPerWord) == 0) {  // x' is a multiple of 32: the finished U word goes out, every lane switches words
-                if (rowValid) nrowU[c / kChunksPerWord - 1] = un;
+            if ((c % kCreepChunksPerWord) == 0) {  // x' is a multiple of 32: the finished U word goes out, every lane switches words
+                if (rowValid) nrowU[c / kCreepChunksPerWord - 1] = un;
                 un = 0;
-                const uint32_t nxt = min(c / kChunksPerWord + 2, wLast);
+                const uint32_t nxt = min(c / kCreepChunksPerWord + 2, wLast);
                 dw = dwN; dwN = dwLd; dwLd = drow[nxt];
                 uw = uwN; uwN = uwLd; uwLd = urow[nxt];
                 hw = hwN; hwN = hwLd; hwLd = hrow ? hrow[nxt] : 0u;
@@ -1203,18 +1220,16 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 duw = duwN; duwN = lane_from_below(uwN);
             }
             if (downLdValid) { downB = downLd; downWB = downWLd; downLdValid = false; }
-            if (xpc + 3 * kCh > L) {
-                const uint32_t k = (xpc + 3 * kCh - L) >> 6;
-                if (k > downIssued) {
-                    downLd = load_block(nrow + 1, k);
-                    downWLd = load_wblock(yBelow, k);
-                    downIssued = k;
-                    downLdValid = true;
-                }
+            if (xpc + 2 * kCreepCh > L && ((xpc + 2 * kCreepCh - L) >> 6) > downIssued) {  // block j + 1 is requested two chunks before the last lane
+                // reaches it and lands in downB at the next event: after block j has moved on to downA, never skipping one
+                ++downIssued;
+                downLd = load_block(nrow + 1, downIssued);
+                downWLd = load_wblock(yBelow, downIssued);
+                downLdValid = true;
             }
             if ((xpc & 63) == 0 && (b == 0 || inGlobal)) { upCur = upLd; upWCur = upWLd; }
-            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
-                const uint32_t k = (xpc + 2 * kCh) >> 6;
+            if ((b == 0 || inGlobal) && ((xpc + 2 * kCreepCh) & 63) == 0) {
+                const uint32_t k = (xpc + 2 * kCreepCh) >> 6;
                 if (inGlobal) wait_above(k);
                 upLd = load_block(0, k);
                 upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
@@ -1225,7 +1240,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 if (lane == 0)
                     lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
                 if (hasBelow) {
-                    const unsigned int limit = xpc + kCh - L;
+                    const unsigned int limit = xpc + kCreepCh - L;
                     while (true) {
                         const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
                         if (limit <= (cns & 0x7FFFFu) + kHandWC) break;
@@ -1236,7 +1251,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             if ((xpc & 63) == 0 && !(b == 0 || inGlobal)) take_above(xpc >> 6, upCur, upWCur);
             load_chunk(c + 2);
         }
-        const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCh - 1, xpEnd);
+        const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCreepCh - 1, xpEnd);
         // A chunk in which no row has a cell that may still change (undefined on entry and not yet updated `repeat` times:
         // neither D nor H) is passed over: nothing is computed, the state the next chunk and the band below need is taken
         // from the ring and the masks.  After the first sweeps that is most of the field.
@@ -1250,36 +1265,38 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 const uint32_t xpk = xp0 + lane;
                 const int64_t xk = (int64_t)xpk - L;
                 if (xpk <= xp1 && xk >= 1 && xk <= (int64_t)C) {
-                    handOut[(uint32_t)xk % kHandWC] = ring[L * kPitch + (xpk & (kRingW - 1))];
+                    handOut[(uint32_t)xk % kHandWC] = ring[L * kCreepPitch + (xpk & (kCreepRingW - 1))];
                     handOutW[(uint32_t)xk % kHandWC] = ((dL >> (xpk & 31)) & 1u) ? 2 : ((uL >> (xpk & 31)) & 1u);
                 }
             }
-            prevRes = ringRow[xp1 & (kRingW - 1)];
+            prevRes = ringRow[xp1 & (kCreepRingW - 1)];
             prevW = ((dw >> (xp1 & 31)) & 1u) ? swf : (float)((uw >> (xp1 & 31)) & 1u);
-            prevRight = ringRow[(xp1 + 1) & (kRingW - 1)];
+            prevRight = ringRow[(xp1 + 1) & (kCreepRingW - 1)];
             continue;
         }
         if (interior(c) && xpc > (uint32_t)kWave) {
-            // ---- every lane is at an interior cell with x >= 2: unrolled, no range tests, mask bits as 17-bit windows
-            const uint32_t half = xpc & kCh;
+            // ---- every lane is at an interior cell with x >= 2: unrolled, no range tests, mask bits as (kCreepCh + 1)-bit windows
+            const uint32_t half = xpc & kCreepCh;
             float* rc = ringRow + half;
             const float* rb = ringBelow + half;
-            const uint32_t rNext = (half ^ kCh);
+            const uint32_t rNext = (half ^ kCreepCh);
             const uint32_t sh0 = xpc & 31, up0 = xpc & 63;
             const uint32_t kSwitch = (L - xpc) & 63;
-            const bool switches = kSwitch < (uint32_t)kCh;
+            const bool switches = kSwitch < (uint32_t)kCreepCh;
             const int dBase = (int)((xpc - L) & 63);
             // bit k: the cell of step k, bit k + 1: its right neighbour (own row) / the cell below (row of lane + 1)
-            const uint32_t d17 = __builtin_amdgcn_alignbit(dwN, dw, sh0), u17 = __builtin_amdgcn_alignbit(uwN, uw, sh0), h16 = hw >> sh0;
-            const uint32_t dd17 = __builtin_amdgcn_alignbit(ddwN, ddw, sh0), du17 = __builtin_amdgcn_alignbit(duwN, duw, sh0);
+            // (kCreepCh + 1)-bit windows of the word pairs, as 64-bit values: the right neighbour of the chunk's last column is bit kCreepCh
+            const uint64_t d17 = (((uint64_t)dwN << 32) | dw) >> sh0, u17 = (((uint64_t)uwN << 32) | uw) >> sh0;
+            const uint64_t dd17 = (((uint64_t)ddwN << 32) | ddw) >> sh0, du17 = (((uint64_t)duwN << 32) | duw) >> sh0;
+            const uint32_t h16 = hw >> sh0;
             uint32_t newBits = 0;
 #pragma unroll
-            for (int k = 0; k < kCh; ++k) {
+            for (int k = 0; k < kCreepCh; ++k) {
                 const bool cD = (d17 >> k) & 1u, cU = (u17 >> k) & 1u, cH = (h16 >> k) & 1u;
                 const float wr = ((d17 >> (k + 1)) & 1u) ? swf : (((u17 >> (k + 1)) & 1u) ? 1.f : 0.f);
                 float wd = ((dd17 >> (k + 1)) & 1u) ? swf : (((du17 >> (k + 1)) & 1u) ? 1.f : 0.f);
-                const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
-                float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                const float right = (k < kCreepCh - 1) ? rc[k + 1] : ringRow[rNext];
+                float down = (k < kCreepCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;
                 float up = lane_from_above(prevRes), wu = lane_from_above(prevW);
                 const float upFirst = lane_value(upCur, (int)(up0 + k)), wuFirst = lane_value(upWCur, (int)(up0 + k));
@@ -1304,10 +1321,10 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             if (switches) { downA = downB; downWA = downWB; }
             un |= newBits << sh0;
             {
-                const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)d17, (int)L), nL = (uint32_t)__builtin_amdgcn_readlane((int)newBits, (int)L);
-                if (lane < (uint32_t)kCh) {
+                const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d17, (int)L), nL = (uint32_t)__builtin_amdgcn_readlane((int)newBits, (int)L);
+                if (lane < (uint32_t)kCreepCh) {
                     const uint32_t xk = xpc + lane - L;
-                    handOut[xk % kHandWC] = ring[L * kPitch + ((xpc + lane) & (kRingW - 1))];
+                    handOut[xk % kHandWC] = ring[L * kCreepPitch + ((xpc + lane) & (kCreepRingW - 1))];
                     handOutW[xk % kHandWC] = ((dL >> lane) & 1u) ? 2 : ((nL >> lane) & 1u);
                 }
             }
@@ -1324,7 +1341,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             const bool cD = dPair & 1u, cU = uPair & 1u, cH = (hw >> sh) & 1u;
             const float wr = (dPair & 2u) ? swf : ((uPair & 2u) ? 1.f : 0.f);
             float wd = (ddPair & 2u) ? swf : ((duPair & 2u) ? 1.f : 0.f);
-            const uint32_t rp = (xp + 1) & (kRingW - 1);
+            const uint32_t rp = (xp + 1) & (kCreepRingW - 1);
             const float right = ringRow[rp];
             float down = ringBelow[rp];
             const float center = prevRight;
@@ -1343,7 +1360,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             const float res = act ? v : center;
             const bool newU = cU || act;
             if (inRange) {
-                if (act) { ringRow[xp & (kRingW - 1)] = res; changed = 1; }
+                if (act) { ringRow[xp & (kCreepRingW - 1)] = res; changed = 1; }
                 if (lane == L) {
                     handOut[(uint32_t)x % kHandWC] = res;
                     handOutW[(uint32_t)x % kHandWC] = cD ? 2 : (newU ? 1 : 0);
@@ -1356,7 +1373,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         }
     }
     flush_chunk(nChunks - 1);
-    if (rowValid) nrowU[(nChunks - 1) / kChunksPerWord] = un;
+    if (rowValid) nrowU[(nChunks - 1) / kCreepChunksPerWord] = un;
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
 }
@@ -1368,7 +1385,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
     __shared__ float shDefault;
     float* rings = smem;
     HandoffC hand;
-    hand.data = smem + kCreepWaves * kWave * kPitch;
+    hand.data = smem + kCreepWaves * kWave * kCreepPitch;
     hand.wcode = reinterpret_cast<unsigned char*>(hand.data + kCreepWaves * 2 * kHandWC);
     hand.produced = reinterpret_cast<unsigned int*>(hand.wcode + kCreepWaves * 2 * kHandWC);
     hand.consumed = hand.produced + kCreepWaves * 2;
@@ -1420,7 +1437,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
 
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
     const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
-    float* ring = rings + wave * kWave * kPitch;
+    float* ring = rings + wave * kWave * kCreepPitch;
     unsigned long long l = 0;
     int changedInLoop = 1;
     while (repeat > 0 && changedInLoop && l < nDef) {  // :1430 (nothing has r < repeat when repeat is 0)
@@ -1577,7 +1594,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         a.setWeight = (int)setWeight;
         a.sumAlgo = tuning("SUM_ALGO", 1);
         a.skipIdle = tuning("CREEP_SKIP", 1);
-        constexpr size_t ldsBytes = (size_t)kCreepWaves * kWave * kPitch * sizeof(float) + (size_t)kCreepWaves * 2 * kHandWC * (sizeof(float) + 1) +
+        constexpr size_t ldsBytes = (size_t)kCreepWaves * kWave * kCreepPitch * sizeof(float) + (size_t)kCreepWaves * 2 * kHandWC * (sizeof(float) + 1) +
                                     (size_t)kCreepWaves * 4 * sizeof(unsigned int);
         allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
         creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);

@@ -5,11 +5,16 @@
 // PROJ.4 is a third-party library that is not part of the reference tree; the projections are implemented from their
 // published closed forms on the sphere (Snyder, "Map Projections - A Working Manual", USGS PP 1395) with PROJ.4's
 // conventions at the pj_transform boundary: geographic coordinates in radians, projected x = a * x' + x_0, longitudes
-// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, ob_tran + o_proj=longlat.
-// Ellipsoids are not implemented (spherical strings only); anything else fails loudly.
+// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, ob_tran +
+// o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
+// an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
+// (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
+// two sides: a pair of strings that would make pj_transform shift the datum is refused, like everything else not
+// implemented (+units, +to_meter, +pm, +axis, +geoc, +over, grid shifts).
 #include "plan.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <map>
 #include <sstream>
 #include <string>
@@ -25,16 +30,169 @@ constexpr double kSpi = 3.14159265359;  // PROJ.4's adjlon threshold
 constexpr double kEps10 = 1e-10;
 constexpr double kDegToRad = .0174532925199432958;  // proj_api.h DEG_TO_RAD
 
-enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran };
+enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc };
 enum StereMode { kNorth = 0, kSouth, kOblique, kEquatorial };
 
 struct ProjParams {
-    int kind, mode, oblique;
-    double a, lam0, phi0, x0, y0, k0;
-    double akm1, sinph0, cosph0;  // stere
+    int kind, mode, oblique, datum;
+    double a, es, e, lam0, phi0, x0, y0, k0;
+    double akm1, sinph0, cosph0;  // stere (on an ellipsoid: sin, cos of the conformal latitude of the origin)
     double n, c, rho0;            // lcc
     double lamp, sphip, cphip;    // ob_tran
+    double esp, ml0, en[5];       // tmerc
+    double Qn, Zb, cgb[6], cbg[6], utg[6], gtu[6];  // etmerc
+    double towgs84[7];            // only compared between the two sides
 };
+
+struct Ellipsoid { const char* name; double a; bool byB; double shape; };  // pj_ellps.c
+constexpr Ellipsoid kEllipsoids[] = {
+    {"sphere", 6370997.0, true, 6370997.0},  {"WGS84", 6378137.0, false, 298.257223563}, {"GRS80", 6378137.0, false, 298.257222101},
+    {"WGS72", 6378135.0, false, 298.26},     {"GRS67", 6378160.0, false, 298.2471674270}, {"bessel", 6377397.155, false, 299.1528128},
+    {"intl", 6378388.0, false, 297.},        {"clrk66", 6378206.4, true, 6356583.8},      {"clrk80", 6378249.145, false, 293.4663},
+    {"krass", 6378245.0, false, 298.3},      {"airy", 6377563.396, true, 6356256.910},
+};
+
+// pj_tsfn / pj_msfn / pj_phi2 / pj_enfn / pj_mlfn / pj_inv_mlfn
+__host__ __device__ inline double tsfn(double phi, double sinphi, double e)
+{
+    sinphi *= e;
+    return tan(.5 * (kHalfPi - phi)) / pow((1. - sinphi) / (1. + sinphi), .5 * e);
+}
+__host__ __device__ inline double msfn(double sinphi, double cosphi, double es) { return cosphi / sqrt(1. - es * sinphi * sinphi); }
+__host__ __device__ inline double ssfn(double phit, double sinphi, double e)
+{
+    sinphi *= e;
+    return tan(.5 * (kHalfPi + phit)) * pow((1. - sinphi) / (1. + sinphi), .5 * e);
+}
+__device__ inline double phi2(double ts, double e)
+{
+    const double eccnth = .5 * e;
+    double phi = kHalfPi - 2. * atan(ts), dphi;
+    int i = 15;
+    do {
+        const double con = e * sin(phi);
+        dphi = kHalfPi - 2. * atan(ts * pow((1. - con) / (1. + con), eccnth)) - phi;
+        phi += dphi;
+    } while (fabs(dphi) > 1e-10 && --i);
+    return i ? phi : NAN;  // pj_phi2 reports an error after 15 rounds
+}
+void enfn(double es, double* en)
+{
+    constexpr double C00 = 1., C02 = .25, C04 = .046875, C06 = .01953125, C08 = .01068115234375, C22 = .75, C44 = .46875,
+                     C46 = .01302083333333333333, C48 = .00712076822916666666, C66 = .36458333333333333333,
+                     C68 = .00569661458333333333, C88 = .3076171875;
+    double t;
+    en[0] = C00 - es * (C02 + es * (C04 + es * (C06 + es * C08)));
+    en[1] = es * (C22 - es * (C04 + es * (C06 + es * C08)));
+    en[2] = (t = es * es) * (C44 - es * (C46 + es * C48));
+    en[3] = (t *= es) * (C66 - es * C68);
+    en[4] = t * es * C88;
+}
+__host__ __device__ inline double mlfn(double phi, double sphi, double cphi, const double* en)
+{
+    cphi *= sphi;
+    sphi *= sphi;
+    return en[0] * phi - cphi * (en[1] + sphi * (en[2] + sphi * (en[3] + sphi * en[4])));
+}
+__device__ inline double inv_mlfn(double arg, double es, const double* en)
+{
+    const double k = 1. / (1. - es);
+    double phi = arg;
+    for (int i = 10; i; --i) {
+        const double s = sin(phi);
+        double t = 1. - es * s * s;
+        phi -= t = (mlfn(phi, s, cos(phi), en) - arg) * (t * sqrt(t)) * k;
+        if (fabs(t) < 1e-11) return phi;
+    }
+    return NAN;
+}
+
+// PJ_etmerc.c: Clenshaw summation of sum p[k] sin(2 (k+1) B) + B, of the real sine series, and of the complex one
+__host__ __device__ inline double gatg(const double* p1, double B)
+{
+    const double cos2B = 2 * cos(2 * B);
+    double h = 0, h1 = p1[5], h2 = 0;
+    for (int k = 4; k >= 0; --k) {
+        h = -h2 + cos2B * h1 + p1[k];
+        h2 = h1;
+        h1 = h;
+    }
+    return B + h * sin(2 * B);
+}
+inline double clens(const double* a, double argR)
+{
+    const double r = 2 * std::cos(argR);
+    double hr = a[5], hr1 = 0, hr2;
+    for (int k = 4; k >= 0; --k) {
+        hr2 = hr1;
+        hr1 = hr;
+        hr = -hr2 + r * hr1 + a[k];
+    }
+    return std::sin(argR) * hr;
+}
+__device__ inline void clenS(const double* a, double argR, double argI, double& R, double& I)
+{
+    const double sinR = sin(argR), cosR = cos(argR), sinhI = sinh(argI), coshI = cosh(argI);
+    double r = 2 * cosR * coshI, i = -2 * sinR * sinhI;
+    double hr = a[5], hi = 0, hr1 = 0, hi1 = 0, hr2, hi2;
+    for (int k = 4; k >= 0; --k) {
+        hr2 = hr1;
+        hi2 = hi1;
+        hr1 = hr;
+        hi1 = hi;
+        hr = -hr2 + r * hr1 - i * hi1 + a[k];
+        hi = -hi2 + i * hr1 + r * hi1;
+    }
+    r = sinR * coshI;
+    i = cosR * sinhI;
+    R = r * hr - i * hi;
+    I = r * hi + i * hr;
+}
+
+// Engsager & Poder's series to the sixth power of the third flattening (PJ_etmerc.c setup)
+void setup_etmerc(ProjParams& p)
+{
+    const double f = p.es / (1 + std::sqrt(1 - p.es));
+    const double n = f / (2 - f);
+    double np = n;
+    p.cgb[0] = n * (2 + n * (-2 / 3.0 + n * (-2 + n * (116 / 45.0 + n * (26 / 45.0 + n * (-2854 / 675.0))))));
+    p.cbg[0] = n * (-2 + n * (2 / 3.0 + n * (4 / 3.0 + n * (-82 / 45.0 + n * (32 / 45.0 + n * (4642 / 4725.0))))));
+    np *= n;
+    p.cgb[1] = np * (7 / 3.0 + n * (-8 / 5.0 + n * (-227 / 45.0 + n * (2704 / 315.0 + n * (2323 / 945.0)))));
+    p.cbg[1] = np * (5 / 3.0 + n * (-16 / 15.0 + n * (-13 / 9.0 + n * (904 / 315.0 + n * (-1522 / 945.0)))));
+    np *= n;
+    p.cgb[2] = np * (56 / 15.0 + n * (-136 / 35.0 + n * (-1262 / 105.0 + n * (73814 / 2835.0))));
+    p.cbg[2] = np * (-26 / 15.0 + n * (34 / 21.0 + n * (8 / 5.0 + n * (-12686 / 2835.0))));
+    np *= n;
+    p.cgb[3] = np * (4279 / 630.0 + n * (-332 / 35.0 + n * (-399572 / 14175.0)));
+    p.cbg[3] = np * (1237 / 630.0 + n * (-12 / 5.0 + n * (-24832 / 14175.0)));
+    np *= n;
+    p.cgb[4] = np * (4174 / 315.0 + n * (-144838 / 6237.0));
+    p.cbg[4] = np * (-734 / 315.0 + n * (109598 / 31185.0));
+    np *= n;
+    p.cgb[5] = np * (601676 / 22275.0);
+    p.cbg[5] = np * (444337 / 155925.0);
+    np = n * n;
+    p.Qn = p.k0 / (1 + n) * (1 + np * (1 / 4.0 + np * (1 / 64.0 + np / 256.0)));
+    p.utg[0] = n * (-0.5 + n * (2 / 3.0 + n * (-37 / 96.0 + n * (1 / 360.0 + n * (81 / 512.0 + n * (-96199 / 604800.0))))));
+    p.gtu[0] = n * (0.5 + n * (-2 / 3.0 + n * (5 / 16.0 + n * (41 / 180.0 + n * (-127 / 288.0 + n * (7891 / 37800.0))))));
+    p.utg[1] = np * (-1 / 48.0 + n * (-1 / 15.0 + n * (437 / 1440.0 + n * (-46 / 105.0 + n * (1118711 / 3870720.0)))));
+    p.gtu[1] = np * (13 / 48.0 + n * (-3 / 5.0 + n * (557 / 1440.0 + n * (281 / 630.0 + n * (-1983433 / 1935360.0)))));
+    np *= n;
+    p.utg[2] = np * (-17 / 480.0 + n * (37 / 840.0 + n * (209 / 4480.0 + n * (-5569 / 90720.0))));
+    p.gtu[2] = np * (61 / 240.0 + n * (-103 / 140.0 + n * (15061 / 26880.0 + n * (167603 / 181440.0))));
+    np *= n;
+    p.utg[3] = np * (-4397 / 161280.0 + n * (11 / 504.0 + n * (830251 / 7257600.0)));
+    p.gtu[3] = np * (49561 / 161280.0 + n * (-179 / 168.0 + n * (6601661 / 7257600.0)));
+    np *= n;
+    p.utg[4] = np * (-4583 / 161280.0 + n * (108847 / 3991680.0));
+    p.gtu[4] = np * (34729 / 80640.0 + n * (-3418889 / 1995840.0));
+    np *= n;
+    p.utg[5] = np * (-20648693 / 638668800.0);
+    p.gtu[5] = np * (212378941 / 319334400.0);
+    const double Z = gatg(p.cbg, p.phi0);
+    p.Zb = -p.Qn * (Z + clens(p.gtu, 2 * Z));
+}
 
 bool geographic_name(const std::string& n) { return n == "latlong" || n == "longlat" || n == "latlon" || n == "lonlat"; }
 
@@ -61,15 +219,53 @@ ProjParams parse_proj4(const char* text)
     auto rad = [&](const char* k, double d) { return has(k) ? num(k, 0) * kPi / 180.0 : d; };
     if (!has("proj")) throw Error("projection string without +proj: " + proj4);
     const std::string name = par["proj"];
+    for (const char* k : {"geoc", "over", "pm", "axis", "to_meter", "vto_meter", "nadgrids", "geoidgrids", "R_A", "R_V", "R_a", "R_g", "R_h",
+                          "R_lat_a", "R_lat_g"})
+        if (has(k)) throw Error("projection parameter +" + std::string(k) + " is not implemented: " + proj4);
+    if (has("units") && par["units"] != "m") throw Error("projection +units other than m are not implemented: " + proj4);
     ProjParams p{};
+    // pj_ell_set: an explicit +a wins over the one +ellps implies; the shape is the first of +es +e +rf +f +b
     p.a = 1;
+    p.datum = has("datum") || has("towgs84");
+    if (has("towgs84")) {
+        std::istringstream list(par["towgs84"]);
+        std::string item;
+        for (int i = 0; i < 7 && std::getline(list, item, ','); ++i) {
+            try { p.towgs84[i] = std::stod(item); } catch (...) { throw Error("+towgs84 is not a list of numbers: " + proj4); }
+        }
+    }
     if (has("R")) p.a = num("R", 1);
-    else if (has("a")) {
-        const bool sphere = (!has("e") || num("e", 0) == 0.0) && !has("b") && !has("rf") && !has("f") && (!has("ellps") || par["ellps"] == "sphere");
-        if (!sphere) throw Error("ellipsoidal projections are not implemented: " + proj4);
-        p.a = num("a", 1);
-    } else if (has("ellps") && par["ellps"] == "sphere") p.a = 6370997.0;
-    else if (!geographic_name(name)) throw Error("ellipsoidal projections are not implemented: " + proj4);
+    else {
+        if (has("datum") && !has("ellps")) {
+            if (par["datum"] == "WGS84") par["ellps"] = "WGS84";
+            else if (par["datum"] == "NAD83") par["ellps"] = "GRS80";
+            else throw Error("datum not implemented: " + proj4);
+        }
+        if (has("ellps")) {
+            const Ellipsoid* ell = nullptr;
+            for (const Ellipsoid& cand : kEllipsoids)
+                if (par["ellps"] == cand.name) ell = &cand;
+            if (!ell) throw Error("ellipsoid not implemented: " + proj4);
+            char buf[64];
+            if (!has("a")) { std::snprintf(buf, sizeof buf, "%.17g", ell->a); par["a"] = buf; }
+            if (!has("es") && !has("e") && !has("rf") && !has("f") && !has("b")) {
+                std::snprintf(buf, sizeof buf, "%.17g", ell->shape);
+                par[ell->byB ? "b" : "rf"] = buf;
+            }
+        }
+        if (has("a")) {
+            p.a = num("a", 1);
+            if (has("es")) p.es = num("es", 0);
+            else if (has("e")) { p.es = num("e", 0); p.es *= p.es; }
+            else if (has("rf")) { p.es = 1. / num("rf", 1); p.es = p.es * (2. - p.es); }
+            else if (has("f")) { p.es = num("f", 0); p.es = p.es * (2. - p.es); }
+            else if (has("b")) { const double b = num("b", 1); p.es = 1. - (b * b) / (p.a * p.a); }
+            if (!(p.a > 0) || p.es < 0 || p.es >= 1) throw Error("invalid ellipsoid: " + proj4);
+        } else if (!geographic_name(name)) {
+            throw Error("projection string without an ellipsoid (+R, +a or +ellps): " + proj4);
+        }
+    }
+    p.e = std::sqrt(p.es);
     p.lam0 = rad("lon_0", 0);
     p.phi0 = rad("lat_0", 0);
     p.x0 = num("x_0", 0);
@@ -83,7 +279,25 @@ ProjParams parse_proj4(const char* text)
         const double t = std::fabs(p.phi0);
         if (std::fabs(t - kHalfPi) < kEps10) p.mode = p.phi0 < 0 ? kSouth : kNorth;
         else p.mode = t > kEps10 ? kOblique : kEquatorial;
-        if (p.mode == kNorth || p.mode == kSouth) {
+        if (p.es != 0) {
+            if (p.mode == kEquatorial) throw Error("the equatorial stereographic projection is implemented on the sphere only: " + proj4);
+            if (p.mode == kNorth || p.mode == kSouth) {
+                if (std::fabs(phits - kHalfPi) < kEps10) p.akm1 = 2. * p.k0 / std::sqrt(std::pow(1 + p.e, 1 + p.e) * std::pow(1 - p.e, 1 - p.e));
+                else {
+                    double t = std::sin(phits);
+                    p.akm1 = std::cos(phits) / tsfn(phits, t, p.e);
+                    t *= p.e;
+                    p.akm1 /= std::sqrt(1. - t * t);
+                }
+            } else {
+                double t = std::sin(p.phi0);
+                const double X = 2. * std::atan(ssfn(p.phi0, t, p.e)) - kHalfPi;
+                t *= p.e;
+                p.akm1 = 2. * p.k0 * std::cos(p.phi0) / std::sqrt(1. - t * t);
+                p.sinph0 = std::sin(X);
+                p.cosph0 = std::cos(X);
+            }
+        } else if (p.mode == kNorth || p.mode == kSouth) {
             p.akm1 = (std::fabs(phits - kHalfPi) >= kEps10) ? std::cos(phits) / std::tan(kFortPi - .5 * phits) : 2. * p.k0;
         } else {
             p.sinph0 = std::sin(p.phi0);
@@ -95,17 +309,68 @@ ProjParams parse_proj4(const char* text)
         const double phi1 = rad("lat_1", 0);
         const double phi2 = has("lat_2") ? rad("lat_2", phi1) : phi1;
         if (!has("lat_0")) p.phi0 = phi1;
-        const double cosphi = std::cos(phi1);
-        p.n = std::sin(phi1);
-        if (std::fabs(phi1 - phi2) >= kEps10)
-            p.n = std::log(cosphi / std::cos(phi2)) / std::log(std::tan(kFortPi + .5 * phi2) / std::tan(kFortPi + .5 * phi1));
-        p.c = cosphi * std::pow(std::tan(kFortPi + .5 * phi1), p.n) / p.n;
-        p.rho0 = (std::fabs(std::fabs(p.phi0) - kHalfPi) < kEps10) ? 0. : p.c * std::pow(std::tan(kFortPi + .5 * p.phi0), -p.n);
+        if (std::fabs(phi1 + phi2) < kEps10) throw Error("lcc: lat_1 = -lat_2: " + proj4);
+        const double sinphi = std::sin(phi1), cosphi = std::cos(phi1);
+        const bool secant = std::fabs(phi1 - phi2) >= kEps10;
+        p.n = sinphi;
+        if (p.es != 0) {
+            const double m1 = msfn(sinphi, cosphi, p.es), ml1 = tsfn(phi1, sinphi, p.e);
+            if (secant) {
+                const double sinphi2 = std::sin(phi2);
+                p.n = std::log(m1 / msfn(sinphi2, std::cos(phi2), p.es));
+                p.n /= std::log(ml1 / tsfn(phi2, sinphi2, p.e));
+            }
+            p.c = p.rho0 = m1 * std::pow(ml1, -p.n) / p.n;
+            p.rho0 *= (std::fabs(std::fabs(p.phi0) - kHalfPi) < kEps10) ? 0. : std::pow(tsfn(p.phi0, std::sin(p.phi0), p.e), p.n);
+        } else {
+            if (secant) p.n = std::log(cosphi / std::cos(phi2)) / std::log(std::tan(kFortPi + .5 * phi2) / std::tan(kFortPi + .5 * phi1));
+            p.c = cosphi * std::pow(std::tan(kFortPi + .5 * phi1), p.n) / p.n;
+            p.rho0 = (std::fabs(std::fabs(p.phi0) - kHalfPi) < kEps10) ? 0. : p.c * std::pow(std::tan(kFortPi + .5 * p.phi0), -p.n);
+        }
     } else if (name == "merc") {
         p.kind = kMerc;
-        if (has("lat_ts")) p.k0 = std::cos(std::fabs(rad("lat_ts", 0)));
+        if (has("lat_ts")) {
+            const double phits = std::fabs(rad("lat_ts", 0));
+            if (phits >= kHalfPi) throw Error("merc: lat_ts >= 90: " + proj4);
+            p.k0 = p.es != 0 ? msfn(std::sin(phits), std::cos(phits), p.es) : std::cos(phits);
+        }
+    } else if (name == "tmerc" || name == "utm" || name == "etmerc") {
+        // utm is etmerc since PROJ.4 4.9.3 (the release debian_bionic/control builds against) and tmerc before; the two
+        // differ by < 1 mm within 6 degrees of the meridian, but only etmerc inverts itself far from it
+        p.kind = name == "tmerc" ? kTmerc : kEtmerc;
+        if (name == "utm") {  // PJ_tmerc.c / PJ_etmerc.c, utm entry
+            if (p.es == 0) throw Error("utm needs an ellipsoid: " + proj4);
+            p.y0 = has("south") ? 10000000. : 0.;
+            p.x0 = 500000.;
+            long zone;
+            if (has("zone")) {
+                zone = (long)num("zone", 0);
+                if (zone < 1 || zone > 60) throw Error("invalid UTM zone: " + proj4);
+                --zone;
+            } else {
+                double l = p.lam0;
+                if (std::fabs(l) > kSpi) { l += kPi; l -= 2 * kPi * std::floor(l / (2 * kPi)); l -= kPi; }
+                zone = (long)std::floor((l + kPi) * 30. / kPi);
+                zone = zone < 0 ? 0 : (zone >= 60 ? 59 : zone);
+            }
+            p.lam0 = (zone + .5) * kPi / 30. - kPi;
+            p.k0 = 0.9996;
+            p.phi0 = 0.;
+        }
+        if (p.kind == kEtmerc) {
+            if (p.es == 0) throw Error("etmerc needs an ellipsoid: " + proj4);
+            setup_etmerc(p);
+        } else if (p.es != 0) {
+            enfn(p.es, p.en);
+            p.ml0 = mlfn(p.phi0, std::sin(p.phi0), std::cos(p.phi0), p.en);
+            p.esp = p.es / (1. - p.es);
+        } else {
+            p.esp = p.k0;
+            p.ml0 = .5 * p.esp;
+        }
     } else if (name == "ob_tran") {
         p.kind = kObTran;
+        if (p.es != 0) throw Error("ob_tran is implemented on the sphere only: " + proj4);
         if (!has("o_proj") || !geographic_name(par["o_proj"]) || !has("o_lat_p"))
             throw Error("ob_tran is implemented for +o_proj=longlat +o_lat_p only: " + proj4);
         p.lamp = rad("o_lon_p", 0);
@@ -133,7 +398,22 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
     if (p.kind == kLatLong) { x = lon; y = lat; return; }
     double lam = adjlon(lon - p.lam0), phi = lat;
     double px = 0, py = 0;
-    if (p.kind == kStere) {
+    if (p.kind == kStere && p.es != 0) {  // PJ_stere.c e_forward
+        const double sinlam = sin(lam);
+        double coslam = cos(lam), sinphi = sin(phi);
+        if (p.mode == kOblique) {
+            const double X = 2. * atan(ssfn(phi, sinphi, p.e)) - kHalfPi;
+            const double sinX = sin(X), cosX = cos(X);
+            const double A = p.akm1 / (p.cosph0 * (1. + p.sinph0 * sinX + p.cosph0 * cosX * coslam));
+            py = A * (p.cosph0 * sinX - p.sinph0 * cosX * coslam);
+            px = A * cosX;
+        } else {
+            if (p.mode == kSouth) { phi = -phi; coslam = -coslam; sinphi = -sinphi; }
+            px = p.akm1 * tsfn(phi, sinphi, p.e);
+            py = -px * coslam;
+        }
+        px *= sinlam;
+    } else if (p.kind == kStere) {
         const double sinlam = sin(lam);
         double coslam = cos(lam);
         if (p.mode == kNorth || p.mode == kSouth) {
@@ -154,13 +434,56 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
             }
         }
     } else if (p.kind == kLcc) {
-        const double rho = (fabs(fabs(phi) - kHalfPi) < kEps10) ? 0. : p.c * pow(tan(kFortPi + .5 * phi), -p.n);
+        const double rho = (fabs(fabs(phi) - kHalfPi) < kEps10) ? 0.
+                           : p.c * (p.es != 0 ? pow(tsfn(phi, sin(phi), p.e), p.n) : pow(tan(kFortPi + .5 * phi), -p.n));
         lam *= p.n;
         px = p.k0 * (rho * sin(lam));
         py = p.k0 * (p.rho0 - rho * cos(lam));
     } else if (p.kind == kMerc) {
         px = p.k0 * lam;
-        py = p.k0 * log(tan(kFortPi + .5 * phi));
+        py = p.es != 0 ? -p.k0 * log(tsfn(phi, sin(phi), p.e)) : p.k0 * log(tan(kFortPi + .5 * phi));
+    } else if (p.kind == kTmerc) {  // PJ_tmerc.c (4.x): Gauss-Krueger series on the ellipsoid, closed form on the sphere
+        constexpr double FC1 = 1., FC2 = .5, FC3 = .16666666666666666666, FC4 = .08333333333333333333, FC5 = .05,
+                         FC6 = .03333333333333333333, FC7 = .02380952380952380952, FC8 = .01785714285714285714;
+        const double sinphi = sin(phi), cosphi = cos(phi);
+        if (p.es != 0) {
+            if (lam < -kHalfPi || lam > kHalfPi) { px = NAN; py = NAN; }
+            else {
+                double t = fabs(cosphi) > 1e-10 ? sinphi / cosphi : 0.;
+                t *= t;
+                double al = cosphi * lam;
+                const double als = al * al;
+                al /= sqrt(1. - p.es * sinphi * sinphi);
+                const double n = p.esp * cosphi * cosphi;
+                px = p.k0 * al * (FC1 + FC3 * als * (1. - t + n + FC5 * als * (5. + t * (t - 18.) + n * (14. - 58. * t) +
+                                  FC7 * als * (61. + t * (t * (179. - t) - 479.)))));
+                py = p.k0 * (mlfn(phi, sinphi, cosphi, p.en) - p.ml0 + sinphi * al * lam * FC2 * (1. + FC4 * als * (5. - t + n * (9. + 4. * n) +
+                             FC6 * als * (61. + t * (t - 58.) + n * (270. - 330. * t) + FC8 * als * (1385. + t * (t * (543. - t) - 3111.))))));
+            }
+        } else {
+            double b = cosphi * sin(lam);
+            if (fabs(fabs(b) - 1.) <= kEps10) { px = NAN; py = NAN; }
+            else {
+                px = p.ml0 * log((1. + b) / (1. - b));
+                py = cosphi * cos(lam) / sqrt(1. - b * b);
+                b = fabs(py);
+                py = b >= 1. ? 0. : acos(py);
+                if (phi < 0.) py = -py;
+                py = p.esp * (py - p.phi0);
+            }
+        }
+    } else if (p.kind == kEtmerc) {  // PJ_etmerc.c e_forward
+        double Cn = gatg(p.cbg, phi), Ce = lam;                     // geodetic -> Gaussian latitude
+        const double sinCn = sin(Cn), cosCn = cos(Cn), sinCe = sin(Ce), cosCe = cos(Ce);
+        Cn = atan2(sinCn, cosCe * cosCn);                           // -> complementary spherical
+        Ce = atan2(sinCe * cosCn, hypot(sinCn, cosCn * cosCe));
+        Ce = asinh(tan(Ce));
+        double dCn, dCe;
+        clenS(p.gtu, 2 * Cn, 2 * Ce, dCn, dCe);                     // -> normalised ellipsoidal N, E
+        Cn += dCn;
+        Ce += dCe;
+        if (fabs(Ce) <= 2.623395162778) { py = p.Qn * Cn + p.Zb; px = p.Qn * Ce; }
+        else { px = NAN; py = NAN; }
     } else {  // ob_tran + longlat: radians stay radians
         if (p.oblique) {
             const double coslam = cos(lam), sinphi = sin(phi), cosphi = cos(phi);
@@ -188,7 +511,37 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
     if (p.kind == kObTran) { xs = x - p.x0; ys = y - p.y0; }
     else { xs = (x - p.x0) / p.a; ys = (y - p.y0) / p.a; }
     double lam = 0, phi = 0;
-    if (p.kind == kStere) {
+    if (p.kind == kStere && p.es != 0) {  // PJ_stere.c e_inverse
+        const double rho = hypot(xs, ys);
+        double tp, phi_l, halfpi, halfe;
+        if (p.mode == kOblique) {
+            tp = 2. * atan2(rho * p.cosph0, p.akm1);
+            const double cosphi = cos(tp), sinphi = sin(tp);
+            phi_l = rho == 0. ? asin(cosphi * p.sinph0) : asin(cosphi * p.sinph0 + (ys * sinphi * p.cosph0 / rho));
+            tp = tan(.5 * (kHalfPi + phi_l));
+            xs *= sinphi;
+            ys = rho * p.cosph0 * cosphi - ys * p.sinph0 * sinphi;
+            halfpi = kHalfPi;
+            halfe = .5 * p.e;
+        } else {
+            if (p.mode == kNorth) ys = -ys;
+            phi_l = kHalfPi - 2. * atan(tp = -rho / p.akm1);
+            halfpi = -kHalfPi;
+            halfe = -.5 * p.e;
+        }
+        phi = NAN;  // no convergence in 8 rounds: pj_transform reports an error
+        lam = NAN;
+        for (int i = 8; i--; phi_l = phi) {
+            const double sinphi = p.e * sin(phi_l);
+            phi = 2. * atan(tp * pow((1. + sinphi) / (1. - sinphi), halfe)) - halfpi;
+            if (fabs(phi_l - phi) < 1e-10) {
+                if (p.mode == kSouth) phi = -phi;
+                lam = (xs == 0. && ys == 0.) ? 0. : atan2(xs, ys);
+                break;
+            }
+            if (i == 0) phi = NAN;
+        }
+    } else if (p.kind == kStere) {
         const double rh = hypot(xs, ys);
         const double c = 2. * atan(rh / p.akm1);
         const double sinc = sin(c), cosc = cos(c);
@@ -213,7 +566,7 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
         double rho = hypot(xs, ys);
         if (rho != 0.) {
             if (p.n < 0.) { rho = -rho; xs = -xs; ys = -ys; }
-            phi = 2. * atan(pow(p.c / rho, 1. / p.n)) - kHalfPi;
+            phi = p.es != 0 ? phi2(pow(rho / p.c, 1. / p.n), p.e) : 2. * atan(pow(p.c / rho, 1. / p.n)) - kHalfPi;
             lam = atan2(xs, ys) / p.n;
         } else {
             lam = 0.;
@@ -221,7 +574,51 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
         }
     } else if (p.kind == kMerc) {
         lam = xs / p.k0;
-        phi = kHalfPi - 2. * atan(exp(-ys / p.k0));
+        phi = p.es != 0 ? phi2(exp(-ys / p.k0), p.e) : kHalfPi - 2. * atan(exp(-ys / p.k0));
+    } else if (p.kind == kTmerc) {
+        constexpr double FC1 = 1., FC2 = .5, FC3 = .16666666666666666666, FC4 = .08333333333333333333, FC5 = .05,
+                         FC6 = .03333333333333333333, FC7 = .02380952380952380952, FC8 = .01785714285714285714;
+        if (p.es != 0) {
+            phi = inv_mlfn(p.ml0 + ys / p.k0, p.es, p.en);
+            if (fabs(phi) >= kHalfPi) {
+                phi = ys < 0. ? -kHalfPi : kHalfPi;
+                lam = 0.;
+            } else {
+                const double sinphi = sin(phi), cosphi = cos(phi);
+                double t = fabs(cosphi) > 1e-10 ? sinphi / cosphi : 0.;
+                const double n = p.esp * cosphi * cosphi;
+                double con = 1. - p.es * sinphi * sinphi;
+                const double d = xs * sqrt(con) / p.k0;
+                con *= t;
+                t *= t;
+                const double ds = d * d;
+                phi -= (con * ds / (1. - p.es)) * FC2 * (1. - ds * FC4 * (5. + t * (3. - 9. * n) + n * (1. - 4 * n) -
+                        ds * FC6 * (61. + t * (90. - 252. * n + 45. * t) + 46. * n - ds * FC8 * (1385. + t * (3633. + t * (4095. + 1574. * t))))));
+                lam = d * (FC1 - ds * FC3 * (1. + 2. * t + n - ds * FC5 * (5. + t * (28. + 24. * t + 8. * n) + 6. * n -
+                           ds * FC7 * (61. + t * (662. + t * (1320. + 720. * t)))))) / cosphi;
+            }
+        } else {
+            double h = exp(xs / p.esp);
+            const double g = .5 * (h - 1. / h);
+            h = cos(p.phi0 + ys / p.esp);
+            phi = asin(sqrt((1. - h * h) / (1. + g * g)));
+            if (ys < 0. && -phi + p.phi0 < 0.) phi = -phi;  // the hemisphere test of PROJ 4.9 (4.8 and older: y < 0 alone, wrong for lat_0 != 0)
+            lam = (g != 0. || h != 0.) ? atan2(g, h) : 0.;
+        }
+    } else if (p.kind == kEtmerc) {  // PJ_etmerc.c e_inverse
+        double Cn = (ys - p.Zb) / p.Qn, Ce = xs / p.Qn;
+        if (fabs(Ce) <= 2.623395162778) {
+            double dCn, dCe;
+            clenS(p.utg, 2 * Cn, 2 * Ce, dCn, dCe);
+            Cn += dCn;
+            Ce += dCe;
+            Ce = atan(sinh(Ce));
+            const double sinCn = sin(Cn), cosCn = cos(Cn), sinCe = sin(Ce), cosCe = cos(Ce);
+            Ce = atan2(sinCe, cosCe * cosCn);
+            Cn = atan2(sinCn * cosCe, hypot(sinCe, cosCe * cosCn));
+            phi = gatg(p.cgb, Cn);
+            lam = Ce;
+        } else { phi = NAN; lam = NAN; }
     } else {
         if (p.oblique) {
             const double lamr = xs - p.lamp;
@@ -239,7 +636,19 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
     lat = phi;
 }
 
-// pj_transform(src, dst) on one point (no datum shift: both sides are spheres)
+// pj_transform shifts the datum when both sides name one and they differ (pj_compare_datums); that is not implemented
+struct ProjPair { ProjParams src, dst; };
+ProjPair parse_pair(const char* projIn, const char* projOut)
+{
+    const ProjPair pp{parse_proj4(projIn), parse_proj4(projOut)};
+    bool sameShift = true;
+    for (int i = 0; i < 7; ++i) sameShift = sameShift && pp.src.towgs84[i] == pp.dst.towgs84[i];
+    if (pp.src.datum && pp.dst.datum && (pp.src.a != pp.dst.a || pp.src.es != pp.dst.es || !sameShift))
+        throw Error(std::string("a datum shift is not implemented: ") + projIn + " -> " + projOut);
+    return pp;
+}
+
+// pj_transform(src, dst) on one point (geodetic longitude and latitude pass unchanged)
 __device__ __forceinline__ void transform_point(const ProjParams& src, const ProjParams& dst, double& x, double& y)
 {
     double lon, lat;
@@ -324,7 +733,8 @@ uint32_t point_blocks(size_t n)
 
 void launch_project_values(const char* projIn, const char* projOut, double* d_x, double* d_y, size_t n, hipStream_t stream)
 {
-    const ProjParams src = parse_proj4(projIn), dst = parse_proj4(projOut);
+    const ProjPair pair = parse_pair(projIn, projOut);
+    const ProjParams &src = pair.src, &dst = pair.dst;
     if (n == 0) return;
     project_values_kernel<<<point_blocks(n), kBlock, 0, stream>>>(src, dst, d_x, d_y, n);
     FA_HIP(hipGetLastError());
@@ -333,7 +743,8 @@ void launch_project_values(const char* projIn, const char* projOut, double* d_x,
 void launch_project_axes(const char* projIn, const char* projOut, const double* h_xAxis, const double* h_yAxis, size_t ix, size_t iy,
                          double* d_outX, double* d_outY, hipStream_t stream)
 {
-    const ProjParams src = parse_proj4(projIn), dst = parse_proj4(projOut);
+    const ProjPair pair = parse_pair(projIn, projOut);
+    const ProjParams &src = pair.src, &dst = pair.dst;
     if (ix * iy == 0) return;
     FA_REQUIRE(ix <= 0x7FFFFFFFu && iy <= 0x7FFFFFFFu, "axis too long");
     DeviceArray<double> d_axes(ix + iy);
@@ -348,7 +759,8 @@ void launch_project_axes(const char* projIn, const char* projOut, const double* 
 void launch_vector_reproject_matrix(const char* projIn, const char* projOut, const double* h_outXAxis, const double* h_outYAxis,
                                     int xAxisType, int yAxisType, size_t ox, size_t oy, double* d_matrix, hipStream_t stream)
 {
-    const ProjParams in = parse_proj4(projIn), out = parse_proj4(projOut);
+    const ProjPair pair = parse_pair(projIn, projOut);
+    const ProjParams &in = pair.src, &out = pair.dst;
     const size_t n = ox * oy;
     if (n == 0) return;
     FA_REQUIRE(ox <= 0x7FFFFFFFu && oy <= 0x7FFFFFFFu, "axis too long");
@@ -416,7 +828,8 @@ double mesh_delta(const double* inX, size_t ox, size_t oy)
 void launch_vector_reproject_matrix_field(const char* projIn, const char* projOut, const double* h_inX, const double* h_inY, size_t ox,
                                           size_t oy, double* d_matrix, hipStream_t stream)
 {
-    const ProjParams in = parse_proj4(projIn), out = parse_proj4(projOut);
+    const ProjPair pair = parse_pair(projIn, projOut);
+    const ProjParams &in = pair.src, &out = pair.dst;
     const size_t n = ox * oy;
     if (n == 0) return;
     DeviceArray<double> d_in(2 * n), d_out(2 * n);
@@ -436,7 +849,8 @@ void launch_vector_reproject_matrix_field(const char* projIn, const char* projOu
 void launch_vector_reproject_matrix_points(const char* projIn, const char* projOut, int inputIsMetric, const double* h_outX,
                                            const double* h_outY, size_t on, double* d_matrix, hipStream_t stream)
 {
-    const ProjParams in = parse_proj4(projIn), out = parse_proj4(projOut);
+    const ProjPair pair = parse_pair(projIn, projOut);
+    const ProjParams &in = pair.src, &out = pair.dst;
     if (on == 0) return;
     DeviceArray<double> d_in(2 * on), d_out(2 * on);
     FA_HIP(hipMemcpyAsync(d_out.get(), h_outX, on * sizeof(double), hipMemcpyHostToDevice, stream));

@@ -12,15 +12,20 @@ Working Manual", USGS PP 1395: stereographic eq. 21-2..21-4, 20-14..20-18;
 Lambert conformal conic eq. 15-1..15-5; oblique transformation eq. 5-7..5-10b)
 with PROJ.4's conventions: longitude/latitude in radians at the pj_transform
 boundary, x = a*x' + x_0, lam = lon - lon_0 wrapped to [-pi, pi].
-Only spheres are covered (+R, or +a with +e=0 / +ellps=sphere): every projection
-string in the reference's tests for this path is spherical except the UTM case
-of test/testInterpolator.cc:430-432, which is out of scope here.
+Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered for
+merc, lcc, polar and oblique stere, tmerc and utm (the UTM zone 33 / WGS84 string
+of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
+7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
+latitude pass unchanged between the two sides (no datum shift is restated; a pair
+of strings that would need one is refused).
 
 Pins (tests/test_oracle_kats.py): tests/golden/coordTest.nc stores 2-D
 longitude/latitude for its 11x11 polar-stereographic grid (121 points);
 tests/golden/outData.txt holds the 180x90 nearest-neighbour output of the EMEP
 polar-stereographic -> lat/lon chain of test/testInterpolation.cc:280-347.
-Beyond those fixtures: parity unpinned.
+The ellipsoidal forms are pinned only by the worked numerical examples of
+Snyder's appendix A (tests/test_oracle_kats.py), not by a reference fixture.
+Beyond those: parity unpinned.
 """
 import math
 
@@ -51,19 +56,142 @@ def _rad(p, key, default=0.0):
     return math.radians(float(p[key])) if key in p else default
 
 
-def _radius(p):
+# pj_ellps.c: name -> (a, "b" | "rf", value)
+ELLIPSOIDS = {
+    "sphere": (6370997.0, "b", 6370997.0),
+    "WGS84": (6378137.0, "rf", 298.257223563),
+    "GRS80": (6378137.0, "rf", 298.257222101),
+    "WGS72": (6378135.0, "rf", 298.26),
+    "GRS67": (6378160.0, "rf", 298.2471674270),
+    "bessel": (6377397.155, "rf", 299.1528128),
+    "intl": (6378388.0, "rf", 297.),
+    "clrk66": (6378206.4, "b", 6356583.8),
+    "clrk80": (6378249.145, "rf", 293.4663),
+    "krass": (6378245.0, "rf", 298.3),
+    "airy": (6377563.396, "b", 6356256.910),
+}
+DATUMS = {"WGS84": "WGS84", "NAD83": "GRS80"}  # datums without a grid shift: ellipsoid only
+_UNSUPPORTED = ("geoc", "over", "pm", "axis", "to_meter", "vto_meter", "nadgrids", "geoidgrids",
+                "R_A", "R_V", "R_a", "R_g", "R_h", "R_lat_a", "R_lat_g")
+
+
+def _ellipsoid(p):
+    """pj_ell_set: (a, es).  An explicit +a wins over the one +ellps implies; the shape comes from the first of
+    +es, +e, +rf, +f, +b that is present (the ellipsoid's own b / rf counts as given last)."""
+    for k in _UNSUPPORTED:
+        if k in p:
+            raise NotImplementedError("+%s is not restated: %r" % (k, p))
+    if p.get("units", "m") != "m":
+        raise NotImplementedError("+units other than m: %r" % (p,))
     if "R" in p:
-        return float(p["R"])
-    if "a" in p:
-        e = float(p.get("e", 0.0)) if "e" in p else 0.0
-        if p.get("ellps", "sphere") == "sphere" and e == 0.0 and "b" not in p and "rf" not in p and "f" not in p:
-            return float(p["a"])
-        raise NotImplementedError("ellipsoid (only spheres are restated): %r" % (p,))
-    if p.get("ellps") == "sphere":
-        return 6370997.0
-    if p["proj"] in ("latlong", "longlat", "latlon", "lonlat"):
-        return 1.0  # radius is irrelevant for geographic coordinates without datum shift
-    raise NotImplementedError("ellipsoid (only spheres are restated): %r" % (p,))
+        return float(p["R"]), 0.0
+    q = dict(p)
+    if "datum" in q:
+        if q["datum"] not in DATUMS:
+            raise NotImplementedError("datum %s" % q["datum"])
+        q.setdefault("ellps", DATUMS[q["datum"]])
+    if "ellps" in q:
+        if q["ellps"] not in ELLIPSOIDS:
+            raise NotImplementedError("ellipsoid %s" % q["ellps"])
+        a, shape, value = ELLIPSOIDS[q["ellps"]]
+        q.setdefault("a", a)
+        if not any(k in q for k in ("es", "e", "rf", "f", "b")):
+            q[shape] = value
+    if "a" not in q:
+        if is_latlong(p):
+            return 1.0, 0.0  # PROJ.4 would default to WGS84; without a datum shift geographic coordinates ignore it
+        raise NotImplementedError("no ellipsoid in %r" % (p,))
+    a = float(q["a"])
+    if "es" in q:
+        es = float(q["es"])
+    elif "e" in q:
+        es = float(q["e"]) ** 2
+    elif "rf" in q:
+        es = 1. / float(q["rf"])
+        es = es * (2. - es)
+    elif "f" in q:
+        es = float(q["f"])
+        es = es * (2. - es)
+    elif "b" in q:
+        b = float(q["b"])
+        es = 1. - (b * b) / (a * a)
+    else:
+        es = 0.0
+    return a, es
+
+
+def has_datum(p):
+    return "datum" in p or "towgs84" in p
+
+
+def _towgs84(p):
+    vals = [float(v) for v in p["towgs84"].split(",")] if "towgs84" in p else []
+    return (vals + [0.] * 7)[:7]
+
+
+def tsfn(phi, sinphi, e):
+    """pj_tsfn, Snyder eq. 7-10 / 15-9."""
+    con = e * sinphi
+    return np.tan(.5 * (HALFPI - phi)) / np.power((1. - con) / (1. + con), .5 * e)
+
+
+def msfn(sinphi, cosphi, es):
+    """pj_msfn, Snyder eq. 14-15."""
+    return cosphi / np.sqrt(1. - es * sinphi * sinphi)
+
+
+def phi2(ts, e):
+    """pj_phi2: latitude from the isometric-latitude function, Snyder eq. 7-9, at most 15 rounds, 1e-10."""
+    ts = np.asarray(ts, dtype=np.float64)
+    phi = HALFPI - 2. * np.arctan(ts)
+    live = np.ones(phi.shape, dtype=bool)
+    for _ in range(15):
+        con = e * np.sin(phi)
+        dphi = HALFPI - 2. * np.arctan(ts * np.power((1. - con) / (1. + con), .5 * e)) - phi
+        phi = np.where(live, phi + dphi, phi)
+        live = live & (np.abs(dphi) > 1e-10)
+        if not live.any():
+            break
+    return phi
+
+
+def enfn(es):
+    """pj_enfn: coefficients of the meridional distance, Snyder eq. 3-21 regrouped."""
+    c00, c02, c04, c06, c08 = 1., .25, .046875, .01953125, .01068115234375
+    c22, c44, c46, c48 = .75, .46875, .01302083333333333333, .00712076822916666666
+    c66, c68, c88 = .36458333333333333333, .00569661458333333333, .3076171875
+    en = [0.] * 5
+    en[0] = c00 - es * (c02 + es * (c04 + es * (c06 + es * c08)))
+    en[1] = es * (c22 - es * (c04 + es * (c06 + es * c08)))
+    t = es * es
+    en[2] = t * (c44 - es * (c46 + es * c48))
+    t *= es
+    en[3] = t * (c66 - es * c68)
+    en[4] = t * es * c88
+    return en
+
+
+def mlfn(phi, sphi, cphi, en):
+    cphi = cphi * sphi
+    sphi = sphi * sphi
+    return en[0] * phi - cphi * (en[1] + sphi * (en[2] + sphi * (en[3] + sphi * en[4])))
+
+
+def inv_mlfn(arg, es, en):
+    """pj_inv_mlfn: Newton on the meridional distance, at most 10 rounds, 1e-11."""
+    arg = np.asarray(arg, dtype=np.float64)
+    k = 1. / (1. - es)
+    phi = arg.copy()
+    live = np.ones(phi.shape, dtype=bool)
+    for _ in range(10):
+        s = np.sin(phi)
+        t = 1. - es * s * s
+        t = (mlfn(phi, s, np.cos(phi), en) - arg) * (t * np.sqrt(t)) * k
+        phi = np.where(live, phi - t, phi)
+        live = live & (np.abs(t) >= 1e-11)
+        if not live.any():
+            break
+    return phi
 
 
 def adjlon(lon):
@@ -81,7 +209,8 @@ class _Proj:
     def __init__(self, projstr):
         self.p = parse(projstr)
         self.name = self.p["proj"]
-        self.a = _radius(self.p)
+        self.a, self.es = _ellipsoid(self.p)
+        self.e = math.sqrt(self.es)
         self.lam0 = _rad(self.p, "lon_0")
         self.phi0 = _rad(self.p, "lat_0")
         self.x0 = float(self.p.get("x_0", 0.0))
@@ -93,7 +222,7 @@ class _Proj:
     def _kind(self):
         if self.latlong:
             return "latlong"
-        if self.name in ("stere", "lcc", "ob_tran", "merc"):
+        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm"):
             return self.name
         raise NotImplementedError("projection %s" % self.name)
 
@@ -111,6 +240,25 @@ class _Proj:
         else:
             self.mode = "O" if t > _EPS10 else "E"
         phits = abs(phits)
+        if self.es != 0.:
+            e = self.e
+            if self.mode == "E":
+                raise NotImplementedError("equatorial stereographic on an ellipsoid (PROJ.4 releases differ there)")
+            if self.mode in ("N", "S"):
+                if abs(phits - HALFPI) < _EPS10:
+                    self.akm1 = 2. * self.k0 / math.sqrt(math.pow(1 + e, 1 + e) * math.pow(1 - e, 1 - e))
+                else:
+                    t = math.sin(phits)
+                    self.akm1 = math.cos(phits) / float(tsfn(phits, t, e))
+                    t *= e
+                    self.akm1 /= math.sqrt(1. - t * t)
+            else:
+                t = math.sin(self.phi0)
+                chi = 2. * math.atan(self._ssfn(self.phi0, t)) - HALFPI
+                t *= e
+                self.akm1 = 2. * self.k0 * math.cos(self.phi0) / math.sqrt(1. - t * t)
+                self.sinX1, self.cosX1 = math.sin(chi), math.cos(chi)
+            return
         if self.mode in ("N", "S"):
             if abs(phits - HALFPI) >= _EPS10:
                 self.akm1 = math.cos(phits) / math.tan(FORTPI - .5 * phits)
@@ -120,7 +268,59 @@ class _Proj:
             self.sinph0, self.cosph0 = math.sin(self.phi0), math.cos(self.phi0)
             self.akm1 = 2. * self.k0
 
+    def _ssfn(self, phit, sinphi):
+        """tan of half the conformal colatitude's complement, Snyder eq. 3-1"""
+        con = self.e * sinphi
+        return np.tan(.5 * (HALFPI + phit)) * np.power((1. - con) / (1. + con), .5 * self.e)
+
+    def _fwd_stere_ell(self, lam, phi):
+        sinlam, coslam, sinphi = np.sin(lam), np.cos(lam), np.sin(phi)
+        if self.mode == "O":
+            chi = 2. * np.arctan(self._ssfn(phi, sinphi)) - HALFPI
+            sinX, cosX = np.sin(chi), np.cos(chi)
+            A = self.akm1 / (self.cosX1 * (1. + self.sinX1 * sinX + self.cosX1 * cosX * coslam))
+            return A * cosX * sinlam, A * (self.cosX1 * sinX - self.sinX1 * cosX * coslam)
+        if self.mode == "S":
+            phi, coslam, sinphi = -phi, -coslam, -sinphi
+        x = self.akm1 * tsfn(phi, sinphi, self.e)
+        return x * sinlam, -x * coslam
+
+    def _inv_stere_ell(self, x, y):
+        rho = np.hypot(x, y)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.mode == "O":
+                tp = 2. * np.arctan2(rho * self.cosX1, self.akm1)
+                cosphi, sinphi = np.cos(tp), np.sin(tp)
+                phi_l = np.where(rho == 0., np.arcsin(cosphi * self.sinX1),
+                                 np.arcsin(cosphi * self.sinX1 + (y * sinphi * self.cosX1 / rho)))
+                tp = np.tan(.5 * (HALFPI + phi_l))
+                xx = x * sinphi
+                yy = rho * self.cosX1 * cosphi - y * self.sinX1 * sinphi
+                halfpi, halfe = HALFPI, .5 * self.e
+            else:
+                xx, yy = x, (-y if self.mode == "N" else y)
+                tp = -rho / self.akm1
+                phi_l = HALFPI - 2. * np.arctan(tp)
+                halfpi, halfe = -HALFPI, -.5 * self.e
+            phi = phi_l
+            live = np.ones(np.shape(phi_l), dtype=bool)
+            for _ in range(8):
+                sinphi = self.e * np.sin(phi_l)
+                nxt = 2. * np.arctan(tp * np.power((1. + sinphi) / (1. - sinphi), halfe)) - halfpi
+                phi = np.where(live, nxt, phi)
+                live = live & ~(np.abs(phi_l - nxt) < 1e-10)
+                phi_l = np.where(live, nxt, phi_l)
+                if not live.any():
+                    break
+            phi = np.where(live, np.nan, phi)  # no convergence: pj_transform reports an error (HUGE_VAL)
+            if self.mode == "S":
+                phi = -phi
+            lam = np.where((xx == 0.) & (yy == 0.), 0., np.arctan2(xx, yy))
+        return lam, phi
+
     def _fwd_stere(self, lam, phi):
+        if self.es != 0.:
+            return self._fwd_stere_ell(lam, phi)
         sinlam, coslam = np.sin(lam), np.cos(lam)
         if self.mode in ("N", "S"):
             if self.mode == "N":
@@ -135,6 +335,8 @@ class _Proj:
         return k * cosphi * sinlam, k * (self.cosph0 * sinphi - self.sinph0 * cosphi * coslam)
 
     def _inv_stere(self, x, y):
+        if self.es != 0.:
+            return self._inv_stere_ell(x, y)
         rh = np.hypot(x, y)
         c = 2. * np.arctan(rh / self.akm1)
         sinc, cosc = np.sin(c), np.cos(c)
@@ -165,6 +367,17 @@ class _Proj:
             self.phi0 = phi1
         self.n = sinphi = math.sin(phi1)
         cosphi = math.cos(phi1)
+        if self.es != 0.:
+            e = self.e
+            m1 = float(msfn(sinphi, cosphi, self.es))
+            ml1 = float(tsfn(phi1, sinphi, e))
+            if abs(phi1 - phi2) >= _EPS10:
+                self.n = math.log(m1 / float(msfn(math.sin(phi2), math.cos(phi2), self.es)))
+                self.n /= math.log(ml1 / float(tsfn(phi2, math.sin(phi2), e)))
+            self.c = self.rho0 = m1 * math.pow(ml1, -self.n) / self.n
+            self.rho0 *= 0. if abs(abs(self.phi0) - HALFPI) < _EPS10 else \
+                math.pow(float(tsfn(self.phi0, math.sin(self.phi0), e)), self.n)
+            return
         if abs(phi1 - phi2) >= _EPS10:
             self.n = math.log(cosphi / math.cos(phi2)) / math.log(
                 math.tan(FORTPI + .5 * phi2) / math.tan(FORTPI + .5 * phi1))
@@ -174,8 +387,11 @@ class _Proj:
 
     def _fwd_lcc(self, lam, phi):
         with np.errstate(invalid="ignore", divide="ignore"):
-            rho = np.where(np.abs(np.abs(phi) - HALFPI) < _EPS10, 0.,
-                           self.c * np.power(np.tan(FORTPI + .5 * phi), -self.n))
+            if self.es != 0.:
+                scale = np.power(tsfn(phi, np.sin(phi), self.e), self.n)
+            else:
+                scale = np.power(np.tan(FORTPI + .5 * phi), -self.n)
+            rho = np.where(np.abs(np.abs(phi) - HALFPI) < _EPS10, 0., self.c * scale)
         lam = lam * self.n
         return self.k0 * (rho * np.sin(lam)), self.k0 * (self.rho0 - rho * np.cos(lam))
 
@@ -186,21 +402,170 @@ class _Proj:
         if self.n < 0.:
             rho, x, y = -rho, -x, -y
         with np.errstate(invalid="ignore", divide="ignore"):
-            phi = np.where(rho != 0., 2. * np.arctan(np.power(self.c / rho, 1. / self.n)) - HALFPI,
-                           HALFPI if self.n > 0. else -HALFPI)
+            if self.es != 0.:
+                onto = phi2(np.power(np.where(rho != 0., rho, 1.) / self.c, 1. / self.n), self.e)
+            else:
+                onto = 2. * np.arctan(np.power(self.c / rho, 1. / self.n)) - HALFPI
+            phi = np.where(rho != 0., onto, HALFPI if self.n > 0. else -HALFPI)
             lam = np.where(rho != 0., np.arctan2(x, y) / self.n, 0.)
         return lam, phi
 
     # ---- Mercator, sphere
     def _setup_merc(self):
         if "lat_ts" in self.p:
-            self.k0 = math.cos(abs(_rad(self.p, "lat_ts")))
+            phits = abs(_rad(self.p, "lat_ts"))
+            self.k0 = float(msfn(math.sin(phits), math.cos(phits), self.es)) if self.es != 0. else math.cos(phits)
 
     def _fwd_merc(self, lam, phi):
+        if self.es != 0.:
+            return self.k0 * lam, -self.k0 * np.log(tsfn(phi, np.sin(phi), self.e))
         return self.k0 * lam, self.k0 * np.log(np.tan(FORTPI + .5 * phi))
 
     def _inv_merc(self, x, y):
+        if self.es != 0.:
+            return x / self.k0, phi2(np.exp(-y / self.k0), self.e)
         return x / self.k0, HALFPI - 2. * np.arctan(np.exp(-y / self.k0))
+
+    # ---- transverse Mercator (Gauss-Krueger series of PROJ.4 4.x, Snyder eq. 8-9..8-25) and UTM
+    def _setup_utm(self):
+        p = self.p
+        if self.es == 0.:
+            raise ValueError("utm needs an ellipsoid (PROJ.4 error -34)")
+        self.y0 = 10000000. if "south" in p else 0.
+        self.x0 = 500000.
+        if "zone" in p:
+            zone = int(p["zone"])
+            if not 1 <= zone <= 60:
+                raise ValueError("invalid UTM zone")
+            zone -= 1
+        else:
+            zone = int(math.floor((float(adjlon(self.lam0)) + math.pi) * 30. / math.pi))
+            zone = min(max(zone, 0), 59)
+        self.lam0 = (zone + .5) * math.pi / 30. - math.pi
+        self.k0 = 0.9996
+        self.phi0 = 0.
+        self._setup_etmerc()   # PROJ.4 4.9.3 (the release debian_bionic/control builds against): utm is etmerc; before: tmerc
+
+    def _setup_tmerc(self):
+        if self.es != 0.:
+            self.en = enfn(self.es)
+            self.ml0 = float(mlfn(self.phi0, math.sin(self.phi0), math.cos(self.phi0), self.en))
+            self.esp = self.es / (1. - self.es)
+        else:
+            self.esp = self.k0
+            self.ml0 = .5 * self.esp
+
+    def _fwd_tmerc(self, lam, phi):
+        sinphi, cosphi = np.sin(phi), np.cos(phi)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.es == 0.:
+                b = cosphi * np.sin(lam)
+                x = self.ml0 * np.log((1. + b) / (1. - b))
+                y = cosphi * np.cos(lam) / np.sqrt(1. - b * b)
+                y = np.where(np.abs(y) >= 1., 0., np.arccos(np.clip(y, -1., 1.)))
+                y = np.where(phi < 0., -y, y)
+                x = np.where(np.abs(np.abs(b) - 1.) <= _EPS10, np.nan, x)
+                return x, self.esp * (y - self.phi0)
+            t = np.where(np.abs(cosphi) > 1e-10, sinphi / cosphi, 0.)
+            t = t * t
+            al = cosphi * lam
+            als = al * al
+            al = al / np.sqrt(1. - self.es * sinphi * sinphi)
+            n = self.esp * cosphi * cosphi
+            x = self.k0 * al * (1. + als / 6. * (1. - t + n + als / 20. * (
+                5. + t * (t - 18.) + n * (14. - 58. * t) + als / 42. * (61. + t * (t * (179. - t) - 479.)))))
+            y = self.k0 * (mlfn(phi, sinphi, cosphi, self.en) - self.ml0 + sinphi * al * lam * .5 * (
+                1. + als / 12. * (5. - t + n * (9. + 4. * n) + als / 30. * (
+                    61. + t * (t - 58.) + n * (270. - 330. * t) + als / 56. * (1385. + t * (t * (543. - t) - 3111.))))))
+            bad = (lam < -HALFPI) | (lam > HALFPI)  # PROJ.4 >= 4.8 refuses the far side
+            return np.where(bad, np.nan, x), np.where(bad, np.nan, y)
+
+    def _inv_tmerc(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.es == 0.:
+                h = np.exp(x / self.esp)
+                g = .5 * (h - 1. / h)
+                h = np.cos(self.phi0 + y / self.esp)
+                phi = np.arcsin(np.sqrt((1. - h * h) / (1. + g * g)))
+                phi = np.where((y < 0.) & (-phi + self.phi0 < 0.), -phi, phi)  # the hemisphere test of 4.9 (4.8 and older: y < 0 only)
+                lam = np.where((g != 0.) | (h != 0.), np.arctan2(g, h), 0.)
+                return lam, phi
+            phi = inv_mlfn(self.ml0 + y / self.k0, self.es, self.en)
+            sinphi, cosphi = np.sin(phi), np.cos(phi)
+            t = np.where(np.abs(cosphi) > 1e-10, sinphi / cosphi, 0.)
+            n = self.esp * cosphi * cosphi
+            con = 1. - self.es * sinphi * sinphi
+            d = x * np.sqrt(con) / self.k0
+            con = con * t
+            t = t * t
+            ds = d * d
+            phi2_ = phi - (con * ds / (1. - self.es)) * .5 * (1. - ds / 12. * (
+                5. + t * (3. - 9. * n) + n * (1. - 4. * n) - ds / 30. * (
+                    61. + t * (90. - 252. * n + 45. * t) + 46. * n - ds / 56. * (
+                        1385. + t * (3633. + t * (4095. + 1574. * t))))))
+            lam = d * (1. - ds / 6. * (1. + 2. * t + n - ds / 20. * (
+                5. + t * (28. + 24. * t + 8. * n) + 6. * n - ds / 42. * (
+                    61. + t * (662. + t * (1320. + 720. * t)))))) / cosphi
+            polar = np.abs(phi) >= HALFPI
+            return np.where(polar, 0., lam), np.where(polar, np.where(y < 0., -HALFPI, HALFPI), phi2_)
+
+    # ---- extended transverse Mercator (Krueger series to n^6: Engsager & Poder 2007; Karney 2011 eq. 35, 36), stated
+    # here through the closed conformal latitude and plain complex sums instead of PROJ.4's trig series and Clenshaw loops
+    _ALPHA = [  # Karney eq. 35 = PROJ.4 gtu
+        [1 / 2, -2 / 3, 5 / 16, 41 / 180, -127 / 288, 7891 / 37800],
+        [13 / 48, -3 / 5, 557 / 1440, 281 / 630, -1983433 / 1935360],
+        [61 / 240, -103 / 140, 15061 / 26880, 167603 / 181440],
+        [49561 / 161280, -179 / 168, 6601661 / 7257600],
+        [34729 / 80640, -3418889 / 1995840],
+        [212378941 / 319334400]]
+    _BETA = [   # Karney eq. 36 = minus PROJ.4 utg
+        [1 / 2, -2 / 3, 37 / 96, -1 / 360, -81 / 512, 96199 / 604800],
+        [1 / 48, 1 / 15, -437 / 1440, 46 / 105, -1118711 / 3870720],
+        [17 / 480, -37 / 840, -209 / 4480, 5569 / 90720],
+        [4397 / 161280, -11 / 504, -830251 / 7257600],
+        [4583 / 161280, -108847 / 3991680],
+        [20648693 / 638668800]]
+
+    def _setup_etmerc(self):
+        if self.es == 0.:
+            raise ValueError("etmerc needs an ellipsoid (PROJ.4 error -34)")
+        f = self.es / (1. + math.sqrt(1. - self.es))
+        n = f / (2. - f)
+        self.Qn = self.k0 / (1. + n) * (1. + n * n * (1 / 4. + n * n * (1 / 64. + n * n / 256.)))
+        self.alpha = [sum(c * n ** (j + 1 + i) for i, c in enumerate(row)) for j, row in enumerate(self._ALPHA)]
+        self.beta = [sum(c * n ** (j + 1 + i) for i, c in enumerate(row)) for j, row in enumerate(self._BETA)]
+        z = float(self._conformal(np.array([self.phi0]))[0])
+        self.Zb = -self.Qn * (z + sum(a * math.sin(2 * (j + 1) * z) for j, a in enumerate(self.alpha)))
+
+    def _conformal(self, phi):
+        return np.arctan(np.sinh(np.arcsinh(np.tan(phi)) - self.e * np.arctanh(self.e * np.sin(phi))))
+
+    def _fwd_etmerc(self, lam, phi):
+        chi = self._conformal(phi)
+        xi = np.arctan2(np.sin(chi), np.cos(lam) * np.cos(chi))
+        eta = np.arcsinh(np.sin(lam) * np.cos(chi) / np.hypot(np.sin(chi), np.cos(chi) * np.cos(lam)))
+        z = xi + 1j * eta
+        w = z + sum(a * np.sin(2 * (j + 1) * z) for j, a in enumerate(self.alpha))
+        bad = np.abs(w.imag) > 2.623395162778
+        return np.where(bad, np.nan, self.Qn * w.imag), np.where(bad, np.nan, self.Qn * w.real + self.Zb)
+
+    def _inv_etmerc(self, x, y):
+        w = (y - self.Zb) / self.Qn + 1j * (x / self.Qn)
+        bad = np.abs(w.imag) > 2.623395162778
+        z = w - sum(b * np.sin(2 * (j + 1) * w) for j, b in enumerate(self.beta))
+        xi, eta = z.real, z.imag
+        lam = np.arctan2(np.sinh(eta), np.cos(xi))
+        chi = np.arcsin(np.clip(np.sin(xi) / np.cosh(eta), -1., 1.))
+        phi = chi.copy()
+        for _ in range(12):  # geodetic from conformal latitude: fixed point of the closed form (contracts by ~e^2 per round)
+            phi = np.arctan(np.sinh(np.arcsinh(np.tan(chi)) + self.e * np.arctanh(self.e * np.sin(phi))))
+        return np.where(bad, np.nan, lam), np.where(bad, np.nan, phi)
+
+    def _fwd_utm(self, lam, phi):
+        return self._fwd_etmerc(lam, phi)
+
+    def _inv_utm(self, x, y):
+        return self._inv_etmerc(x, y)
 
     # ---- general oblique transformation around a geographic "projection" (rotated pole)
     def _setup_ob_tran(self):
@@ -263,6 +628,8 @@ class _Proj:
 def transform(src, dst, x, y):
     """pj_transform(src, dst, ...): coordinates of src -> coordinates of dst (no datum shift)."""
     ps, pd = _Proj(src), _Proj(dst)
+    if has_datum(ps.p) and has_datum(pd.p) and (ps.a != pd.a or ps.es != pd.es or _towgs84(ps.p) != _towgs84(pd.p)):
+        raise NotImplementedError("a datum shift between %r and %r" % (src, dst))
     lon, lat = ps.inverse(x, y)
     return pd.forward(lon, lat)
 

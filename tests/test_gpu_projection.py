@@ -26,6 +26,21 @@ LCC2 = "+proj=lcc +lat_0=48 +lon_0=8 +lat_1=30 +lat_2=60 +R=6371229"
 MERC = "+proj=merc +lon_0=5 +lat_ts=30 +R=6371000"
 ROT = "+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06 +no_defs"
 ALL = [GEO, STERE, STERE_OBL, STERE_EQ, STERE_S, LCC, LCC2, MERC, ROT]
+# on an ellipsoid (the UTM string is the one of test/testInterpolator.cc:422)
+GEO_W = "+proj=latlong +datum=WGS84"
+UTM33 = "+proj=utm +zone=33 +datum=WGS84 +no_defs"
+ETMERC = "+proj=etmerc +lon_0=-3 +lat_0=49 +k=0.9996012717 +x_0=400000 +y_0=-100000 +ellps=airy"
+UTM17S = "+proj=utm +zone=17 +south +ellps=GRS80"
+TMERC_S = "+proj=tmerc +lon_0=12 +lat_0=0 +k=0.9996 +R=6371000"   # lat_0 != 0 on the sphere: PROJ.4 releases pick the hemisphere differently
+TMERC_B = "+proj=tmerc +lon_0=9 +lat_0=0 +k=1 +x_0=3500000 +ellps=bessel"
+STERE_W = "+proj=stere +lat_0=90 +lon_0=-45 +lat_ts=70 +ellps=WGS84"
+STERE_WS = "+proj=stere +lat_0=-90 +lon_0=0 +lat_ts=-71 +ellps=WGS84"
+STERE_WP = "+proj=stere +lat_0=90 +lon_0=10 +k=0.994 +ellps=intl"
+STERE_WO = "+proj=stere +lat_0=52.156 +lon_0=5.387 +k=0.9999079 +x_0=155000 +y_0=463000 +ellps=bessel"
+LCC_W = "+proj=lcc +lat_0=52 +lon_0=10 +lat_1=35 +lat_2=65 +x_0=4000000 +y_0=2800000 +ellps=GRS80"
+LCC_W1 = "+proj=lcc +lat_0=63 +lon_0=15 +lat_1=63 +a=6378137 +rf=298.257223563"
+MERC_W = "+proj=merc +lon_0=5 +lat_ts=30 +ellps=WGS84"
+ELLIPSOIDAL = [UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
 
 
 @pytest.fixture(scope="module")
@@ -70,10 +85,62 @@ def test_project_axes_between_projections(fa, src, dst):
     _close(gx.ravel(), wx, dst); _close(gy.ravel(), wy, dst)
 
 
+@pytest.mark.parametrize("dst", ELLIPSOIDAL)
+def test_ellipsoidal_projections_from_geographic_and_back(fa, dst):
+    """The series PROJ.4 uses on an ellipsoid (oracle/proj_oracle.py, pinned by Snyder's worked examples in
+    tests/test_oracle_kats.py); transverse Mercator within 12 degrees of its meridian."""
+    rng = np.random.default_rng(len(dst))
+    tm = "tmerc" in dst or "utm" in dst
+    series = "proj=tmerc" in dst   # Gauss-Krueger truncated; utm and etmerc carry the series to n^6 and hold far out
+    lon0 = np.degrees(po._Proj(dst).lam0)
+    lon = np.radians(rng.uniform(lon0 - 12, lon0 + 12, 20000) if series else (rng.uniform(lon0 - 40, lon0 + 40, 20000) if tm else rng.uniform(-60, 80, 20000)))
+    south = dst == STERE_WS
+    lat = np.radians(rng.uniform(-85 if south else (-70 if tm or dst == MERC_W else 20), -30 if south else 85, 20000))
+    x, y = fa.project_values_host(GEO_W, dst, lon, lat)
+    wx, wy = po.transform(GEO_W, dst, lon, lat)
+    atol = 2e-6 if dst == TMERC_S else 2e-8   # metres; the spherical form takes acos of nearly 1 at the equator
+    np.testing.assert_allclose(x, wx, rtol=2e-12, atol=atol); np.testing.assert_allclose(y, wy, rtol=2e-12, atol=atol)
+    bx, by = fa.project_values_host(dst, GEO_W, x, y)
+    wbx, wby = po.transform(dst, GEO_W, x, y)
+    np.testing.assert_allclose(bx, wbx, atol=2e-13); np.testing.assert_allclose(by, wby, atol=2e-13)
+    tol = 2e-7 if series else 2e-10  # the truncated series does not invert itself exactly away from the meridian
+    np.testing.assert_allclose(bx, lon, atol=tol); np.testing.assert_allclose(by, lat, atol=tol)
+    assert not fa.projection_is_degree(dst)
+
+
+def test_snyders_worked_examples_on_the_gpu(fa):
+    from test_oracle_kats import SNYDER
+    for proj, lonlat, xy in SNYDER:
+        x, y = fa.project_values_host("+proj=latlong +ellps=clrk66", proj, np.radians([lonlat[0]]), np.radians([lonlat[1]]))
+        assert abs(x[0] - xy[0]) < 0.1 and abs(y[0] - xy[1]) < 0.1, (proj, x, y)
+
+
+def test_transverse_mercator_refuses_the_far_side(fa):
+    lon, lat = np.radians([15., 120., -100., 15.]), np.radians([60., 60., 10., -30.])
+    tm33 = "+proj=tmerc +lon_0=15 +k=0.9996 +x_0=500000 +ellps=WGS84"
+    x, y = fa.project_values_host(GEO_W, tm33, lon, lat)
+    wx, wy = po.transform(GEO_W, tm33, lon, lat)
+    assert np.array_equal(np.isnan(x), [False, True, True, False]) and np.array_equal(np.isnan(x), np.isnan(wx))
+    assert abs(x[0] - 500000.) < 1e-6 and abs(y[0] - wy[0]) < 1e-7
+
+
+def test_axes_between_an_ellipsoid_and_a_sphere(fa):
+    """pj_transform without datums on either side passes geodetic coordinates unchanged (the arome LCC sphere to UTM 33)."""
+    ax, ay = np.linspace(-2e5, 12e5, 281), np.linspace(62e5, 80e5, 181)
+    gx, gy = fa.project_axes_host(UTM33, LCC, ax, ay)
+    wx, wy = po.project_axes(UTM33, LCC, ax, ay)
+    np.testing.assert_allclose(gx.ravel(), wx, atol=2e-8); np.testing.assert_allclose(gy.ravel(), wy, atol=2e-8)
+
+
 def test_unsupported_projection_strings_fail_loudly(fa):
-    for bad in ("+proj=utm +zone=33 +ellps=WGS84", "+proj=stere +lat_0=90 +ellps=WGS84", "+lat_0=3", "+proj=ob_tran +o_proj=stere +R=1"):
+    for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=0 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84", "+lat_0=3",
+                "+proj=ob_tran +o_proj=stere +R=1", "+proj=ob_tran +o_proj=longlat +o_lat_p=30 +ellps=WGS84", "+proj=merc +ellps=WGS84 +units=km",
+                "+proj=merc +datum=potsdam", "+proj=merc +ellps=nonesuch", "+proj=stere +lat_0=90", "+proj=lcc +lat_1=30 +lat_2=-30 +R=1",
+                "+proj=merc +R=6371000 +pm=oslo", "+proj=omerc +lat_0=60 +R=6371000"):
         with pytest.raises(fa.FimexAmdError):
             fa.project_values_host(GEO, bad, np.zeros(3), np.zeros(3))
+    with pytest.raises(fa.FimexAmdError):  # pj_transform would shift the datum here
+        fa.project_values_host(GEO_W, "+proj=utm +zone=33 +ellps=bessel +towgs84=598.1,73.7,418.2,0.202,0.045,-2.455,6.7", np.zeros(3), np.zeros(3))
 
 
 @pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
@@ -202,3 +269,58 @@ def test_rotate_vector_on_stored_types_and_packed_directions(fa):
     want = ((1 / scale) * (rotated.astype(np.float64) - offset)).astype(np.float32)
     got = vec.reproject_direction_scaled_host(ang, scale, offset)
     assert cases.same(got, want.reshape(got.shape)), cases.describe_mismatch(got, want.reshape(got.shape))
+
+
+BACKFORTH = [  # test/testInterpolator.cc:401-424: projection, its axes, their unit, lon / lat axes of the way back, tolerance
+    ("+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +R=6371000", np.arange(-3e7, 3e7 + 1, 50000.), np.arange(-3e7, 3e7 + 1, 50000.), "m",
+     np.arange(-180., 180.), np.arange(55., 88.), 8e-2),
+    ("+proj=stere +lat_0=-90 +lon_0=0 +lat_ts=-90 +ellps=sphere +R=6371000", np.arange(-3e7, 3e7 + 1, 50000.), np.arange(-3e7, 3e7 + 1, 50000.), "m",
+     np.array([0., 1., 359.]), -np.arange(55., 88.), 8e-2),   # the reference's "0,1,359" is these three meridians
+    ("+proj=lcc +lat_0=63 +lon_0=15 +lat_1=63 +lat_2=63 +no_defs +R=6.371e+06", np.arange(-922000., 922001, 20000.), np.arange(-1130000., 1230001, 20000.), "m",
+     np.arange(-30., 41.), np.arange(50., 86.), 1e-2),
+    ("+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06 +no_defs", np.arange(16.5, 24.25, .1), np.arange(-3.8, 14.95, .1), "degree",
+     np.arange(-30., 41.), np.arange(50., 86.), 5e-3),
+    ("+proj=latlon +R=6.371e+06 +no_defs", np.arange(-179., 180.), np.arange(-89.5, 90., .5), "degree",
+     np.arange(-180., 180.), np.arange(-90., 91.), 1e-3),
+    ("+proj=utm +zone=33 +datum=WGS84 +no_defs", np.arange(-4e5, 14e5 + 1, 2000.), np.arange(55e5, 90e5 + 1, 2000.), "m",
+     np.arange(-30., 41.), np.arange(50., 86.), 1e-2),
+]
+
+
+@pytest.mark.parametrize("wind", [(0., 1.), (1., 0.)], ids=["north", "east"])
+@pytest.mark.parametrize("case", BACKFORTH, ids=["stere", "stere_south", "lcc", "hirlam8", "latlon", "utm33"])
+def test_wind_to_a_projection_and_back(fa, case, wind):
+    """test/testInterpolator.cc:398-472 (test_interpolator_vector_backforth): a constant northward (eastward) wind on a
+    lat/lon grid, regridded (nearest) and rotated into a projection, then regridded and rotated back to lat/lon, is the
+    same wind again within the reference's tolerance.  test/data/north.nc, east.nc are NetCDF-4 (not readable here):
+    the constant fields are re-created on a 1-degree global grid.  Plans and both rotation matrices are built on the device."""
+    proj, xa, ya, unit, lonb, latb, delta = case
+    geo = "+proj=latlon +R=6371000"
+    deg = unit == "degree"
+    slon, slat = np.arange(-180., 181.), np.arange(-90., 91.)
+    u0 = np.full((slat.size, slon.size), wind[0], np.float32)
+    v0 = np.full((slat.size, slon.size), wind[1], np.float32)
+    xr, yr = (np.radians(xa), np.radians(ya)) if deg else (xa, ya)   # src/CDMInterpolator.cc:1443-1451
+    types = (fa.LONGITUDE, fa.LATITUDE) if deg else (fa.PROJ_AXIS, fa.PROJ_AXIS)
+    # there
+    lon, lat = fa.project_axes_host(proj, geo, xr, yr)
+    px = fa.points2position_host(lon.ravel(), np.radians(slon), fa.LONGITUDE)
+    py = fa.points2position_host(lat.ravel(), np.radians(slat), fa.LATITUDE)
+    plan = fa.RegridPlan(oracle.NEAREST, px, py, slon.size, slat.size, xa.size, ya.size)
+    u1, v1 = plan.apply_host(u0), plan.apply_host(v0)
+    m1 = fa.get_vector_reproject_matrix_host(geo, proj, xa, ya, *types)
+    u1, v1 = fa.VectorPlan(m1, xa.size, ya.size).reproject_values_host(u1, v1)
+    assert np.isfinite(np.asarray(u1)).mean() > 0.5
+    # and back
+    qx, qy = fa.project_axes_host(geo, proj, np.radians(lonb), np.radians(latb))
+    bx = fa.points2position_host(qx.ravel(), xr, types[0])
+    by = fa.points2position_host(qy.ravel(), yr, types[1])
+    back = fa.RegridPlan(oracle.NEAREST, bx, by, xa.size, ya.size, lonb.size, latb.size)
+    u2, v2 = back.apply_host(np.asarray(u1, np.float32)), back.apply_host(np.asarray(v1, np.float32))
+    m2 = fa.get_vector_reproject_matrix_host(proj, geo, lonb, latb, fa.LONGITUDE, fa.LATITUDE)
+    u2, v2 = fa.VectorPlan(m2, lonb.size, latb.size).reproject_values_host(u2, v2)
+    u2, v2 = np.ravel(u2), np.ravel(v2)
+    ok = ~(np.isnan(u2) | np.isnan(v2))
+    assert ok.mean() > 0.05, ok.mean()
+    assert np.abs(u2[ok] - wind[0]).max() < delta and np.abs(v2[ok] - wind[1]).max() < delta, \
+        (np.abs(u2[ok] - wind[0]).max(), np.abs(v2[ok] - wind[1]).max())

@@ -288,3 +288,97 @@ def test_extrapolation_variants_of_the_linear_blend():
     assert cases.same(none(0.), A) and cases.same(none(1.), B)   # copies: no 0 * NaN side effects
     assert cases.same(const(7.), B) and cases.same(const(-3.), A) and cases.same(const(.5), A + np.float32(.5) * (B - A))
     assert cases.same(oracle.get_values_1d(oracle.BLEND_NEAREST, A, B, 0., 1., .9)[0], A)
+
+
+# ---------------------------------------------------------------- ellipsoidal projections (testInterpolator.cc:422)
+# Worked numerical examples of Snyder, "Map Projections - A Working Manual" (USGS PP 1395), appendix A: the published
+# known answers the PROJ.4 series are checked against in the absence of the library (values in metres, one decimal).
+SNYDER = [
+    ("+proj=merc +ellps=clrk66 +lon_0=-180", (-75., 35.), (11688673.7, 4139145.6)),
+    ("+proj=tmerc +ellps=clrk66 +lon_0=-75 +lat_0=0 +k=0.9996", (-73.5, 40.5), (127106.5, 4484124.4)),
+    ("+proj=lcc +ellps=clrk66 +lat_1=33 +lat_2=45 +lat_0=23 +lon_0=-96", (-75., 35.), (1894410.9, 1564649.5)),
+    ("+proj=stere +ellps=intl +lat_0=-90 +lat_ts=-71 +lon_0=-100", (150., -75.), (-1540033.6, -560526.4)),
+    ("+proj=stere +ellps=clrk66 +lat_0=40 +lon_0=-100 +k=0.9999", (-90., 30.), (971630.8, -1063049.3)),
+]
+
+
+@pytest.mark.parametrize("proj,lonlat,xy", SNYDER)
+def test_ellipsoidal_forms_reproduce_snyders_worked_examples(proj, lonlat, xy):
+    lon, lat = np.radians([lonlat[0]]), np.radians([lonlat[1]])
+    x, y = po.transform("+proj=latlong +ellps=clrk66", proj, lon, lat)
+    assert abs(x[0] - xy[0]) < 0.1 and abs(y[0] - xy[1]) < 0.1, (x, y)  # printed to one decimal, from a rounded e^2
+    bl, bp = po.transform(proj, "+proj=latlong +ellps=clrk66", x, y)
+    np.testing.assert_allclose([bl[0], bp[0]], [lon[0], lat[0]], atol=2e-10)
+
+
+def test_utm_is_etmerc_of_its_zone_and_central_meridian_arc():
+    """UTM 33 (test/testInterpolator.cc:422): central meridian 15 E, k 0.9996, false easting 500 km; on the central
+    meridian the northing is k times the meridian arc (WGS84 quarter meridian 10 001 965.729 m).  Since PROJ.4 4.9.3
+    utm runs the extended series (etmerc); +proj=tmerc stays the truncated Gauss-Krueger series, and the two meet
+    near the meridian."""
+    geo = "+proj=latlong +datum=WGS84"
+    utm = "+proj=utm +zone=33 +datum=WGS84 +no_defs"
+    etm = "+proj=etmerc +lon_0=15 +k=0.9996 +x_0=500000 +ellps=WGS84"
+    tm = "+proj=tmerc +lon_0=15 +k=0.9996 +x_0=500000 +ellps=WGS84"
+    rng = np.random.default_rng(33)
+    lon, lat = np.radians(rng.uniform(-25, 55, 2000)), np.radians(rng.uniform(-85, 85, 2000))
+    a = po.transform(geo, utm, lon, lat)
+    b = po.transform(geo, etm, lon, lat)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-7); np.testing.assert_allclose(a[1], b[1], atol=1e-7)  # lon_0 = 32.5 pi/30 - pi rounds differently
+    bl, bp = po.transform(utm, geo, a[0], a[1])   # inverts itself 40 degrees from the meridian
+    np.testing.assert_allclose(bl, lon, atol=1e-13); np.testing.assert_allclose(bp, lat, atol=1e-13)
+    for width, tol in ((3, 2e-5), (6, 1e-3)):     # metres between the two series
+        near = np.abs(lon - np.radians(15)) < np.radians(width)
+        c = po.transform(geo, tm, lon[near], lat[near])
+        assert np.hypot(a[0][near] - c[0], a[1][near] - c[1]).max() < tol
+    x, y = po.transform(geo, utm, np.radians([15.]), np.radians([90. - 1e-9]))
+    assert abs(x[0] - 500000.) < 1e-3 and abs(y[0] - 0.9996 * 10001965.729) < 2e-2
+    south = po.transform(geo, "+proj=utm +zone=33 +south +ellps=WGS84", np.radians([15.]), np.radians([0.]))
+    assert abs(south[1][0] - 1e7) < 1e-6
+    x, y = po.transform("+proj=latlong +ellps=clrk66", "+proj=etmerc +ellps=clrk66 +lon_0=-75 +k=0.9996", np.radians([-73.5]), np.radians([40.5]))
+    assert abs(x[0] - 127106.5) < 0.1 and abs(y[0] - 4484124.4) < 0.1   # Snyder's worked example again, through the other series
+    # the truncated series inverts itself only near the meridian
+    tl, tp = po.transform(tm, geo, *po.transform(geo, tm, lon, lat))
+    narrow = np.abs(lon - np.radians(15)) < np.radians(3)
+    np.testing.assert_allclose(tl[narrow], lon[narrow], atol=1e-11); np.testing.assert_allclose(tp[narrow], lat[narrow], atol=1e-11)
+
+
+def test_etmerc_series_for_the_conformal_latitude_on_a_flatter_ellipsoid():
+    """The n^6 series against the closed conformal latitude the oracle uses: they meet to n^7 (here rf = 150)."""
+    geo, etm = "+proj=latlong +a=6378137 +rf=150", "+proj=etmerc +lon_0=0 +a=6378137 +rf=150"
+    rng = np.random.default_rng(5)
+    lon, lat = np.radians(rng.uniform(-30, 30, 500)), np.radians(rng.uniform(-85, 85, 500))
+    x, y = po.transform(geo, etm, lon, lat)
+    bl, bp = po.transform(etm, geo, x, y)
+    np.testing.assert_allclose(bl, lon, atol=5e-13); np.testing.assert_allclose(bp, lat, atol=5e-13)
+
+
+@pytest.mark.parametrize("proj", ["+proj=merc +lon_0=5 +lat_ts=30", "+proj=lcc +lat_0=48 +lon_0=8 +lat_1=30 +lat_2=60",
+                                  "+proj=stere +lat_0=90 +lon_0=0 +lat_ts=60", "+proj=stere +lat_0=52 +lon_0=10", "+proj=tmerc +lon_0=12 +lat_0=20"])
+def test_ellipsoidal_forms_tend_to_the_spherical_ones(proj):
+    """e -> 0: the ellipsoidal series and the closed spherical forms are different code and must meet."""
+    rng = np.random.default_rng(7)
+    lon, lat = np.radians(rng.uniform(2, 22, 300) if "tmerc" in proj else rng.uniform(-15, 35, 300)), np.radians(rng.uniform(25, 80, 300))
+    xs, ys = po.transform("+proj=latlong +R=6371000", proj + " +R=6371000", lon, lat)
+    xe, ye = po.transform("+proj=latlong +R=6371000", proj + " +a=6371000 +es=1e-14", lon, lat)
+    tol = 0.05 if "tmerc" in proj else 1e-3  # tmerc: a truncated series against the closed form, within 10 degrees of the meridian
+    np.testing.assert_allclose(xe, xs, atol=tol); np.testing.assert_allclose(ye, ys, atol=tol)
+
+
+def test_ellipsoid_parameters_follow_pj_ell_set():
+    P = po._Proj
+    assert P("+proj=merc +ellps=WGS84").es == pytest.approx(0.0066943799901413165, rel=1e-14)
+    assert P("+proj=merc +datum=WGS84").a == 6378137.0
+    assert P("+proj=merc +ellps=WGS84 +a=6000000").a == 6000000.0          # an explicit +a wins
+    assert P("+proj=merc +ellps=WGS84 +a=6000000").es == P("+proj=merc +ellps=WGS84").es
+    assert P("+ellps=sphere +a=127.4 +e=0 +proj=stere +lat_0=90").es == 0.0  # the reference's EMEP strings stay spherical
+    assert P("+proj=merc +a=6378137 +b=6356752.314245").es == pytest.approx(0.0066943799901413165, rel=1e-9)
+    assert P("+proj=merc +a=6378137 +f=0.0033528106647474805").es == pytest.approx(0.0066943799901413165, rel=1e-12)
+    assert P("+proj=merc +R=6371000 +ellps=WGS84").es == 0.0                 # +R wins over everything
+    for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=61 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84",
+                "+proj=merc +ellps=WGS84 +units=km", "+proj=merc +datum=potsdam"):
+        with pytest.raises((NotImplementedError, ValueError)):
+            P(bad)
+    with pytest.raises(NotImplementedError):   # would need a datum shift
+        po.transform("+proj=latlong +datum=WGS84", "+proj=utm +zone=33 +ellps=bessel +towgs84=598.1,73.7,418.2,0.202,0.045,-2.455,6.7",
+                     np.zeros(1), np.zeros(1))

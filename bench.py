@@ -225,6 +225,10 @@ def main():
                                               "when repeated, not from HBM)", "kernel_ms_avg": float(np.mean(k1)),
                                   "Mcells_per_s": wl.outX * wl.outY / (float(np.mean(k1)) * 1e-3) / 1e6,
                                   "achieved_GBps": b1 / (float(np.mean(k1)) * 1e-3) / 1e9}
+        # the box's copy ceiling for context: a device-to-device copy of the output's size, read + write bytes
+        flat_in, flat_out = d_in.view(-1)[:d_out.numel()], d_out.view(-1)
+        _, kc = time_launches(torch, lambda: flat_out.copy_(flat_in), 10, 2, False)
+        result["roofline"]["copy_kernel_GBps"] = 8 * d_out.numel() / (float(np.mean(kc)) * 1e-3) / 1e9
         if dist_on:
             # write-back: RCCL gather of every rank's finished slices to rank 0 over xGMI, outside the metric
             from fimex_amd import sharding

@@ -72,6 +72,14 @@ def main():
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     fa.points2position_device(dx.data_ptr(), dx.numel(), fw.x_axis, fa.PROJ_AXIS, st)
     fa.points2position_device(dy.data_ptr(), dy.numel(), fw.y_axis, fa.PROJ_AXIS, st)
+    # bucket occupancy: source cells per target cell, RoundAndClamp positions (half away from zero)
+    rx = torch.copysign(torch.floor(dx.abs() + 0.5), dx).long()
+    ry = torch.copysign(torch.floor(dy.abs() + 0.5), dy).long()
+    inside = (rx >= 0) & (rx < fw.outX) & (ry >= 0) & (ry < fw.outY)
+    per_target = torch.bincount((ry * fw.outX + rx)[inside], minlength=fw.outX * fw.outY)
+    hist = torch.bincount(per_target.clamp(max=8), minlength=9).tolist()
+    occupancy = {("%d" % k if k < 8 else "8+"): hist[k] for k in range(9)}
+    del rx, ry, inside, per_target
     nzf = 20 if args.quick else 100
     d_in = bench.make_slices(torch, fw.base_field(), nzf)
     d_out = torch.empty((nzf, fw.outY, fw.outX), dtype=torch.float32, device="cuda")
@@ -85,7 +93,7 @@ def main():
         bt = nzf * 4 * (info["mappedSourceCells"] + fw.outX * fw.outY) + info["planBytes"]
         emit(mname + " nz=%d 3600x1800->1500x1500" % nzf, ms, mn, b, nzf * fw.inX * fw.inY,
              {"plan_build_s": tb, "frac_if_only_mapped_source_cells_counted": bt / ms / 1e6 / PEAK, "mapped_source_cells": info["mappedSourceCells"], "max_bucket": info["maxBucket"],
-              "empty_targets": info["undefinedCells"], "note": "Mcells/s counts SOURCE cells"})
+              "empty_targets": info["undefinedCells"], "bucket_occupancy": occupancy, "note": "Mcells/s counts SOURCE cells"})
     del d_in, d_out
     # --- C5: fills on 3000x3000 slices with land-mask like holes
     nx = ny = 1000 if args.quick else 3000

@@ -56,7 +56,7 @@ def main():
     ms, mn = timed(torch, lambda: vec.reproject_direction_device(d_u.data_ptr(), nz, st))
     emit("rotate_direction nz=%d 2000x2000" % nz, ms, mn, nz * 8 * n + 8 * n, nz * n)
     ms, mn = timed(torch, lambda: fa.bad2nan_device(d_u.data_ptr(), d_u.numel(), 1e30, st))
-    emit("bad2nan %d floats" % d_u.numel(), ms, mn, 8 * d_u.numel(), d_u.numel())
+    emit("bad2nan %d floats (no fill values met: read only, groups are written back only where one was replaced)" % d_u.numel(), ms, mn, 4 * d_u.numel(), d_u.numel())
     # --- typed slice edges (n1) and 1-D blends (n4) on the same 800 M values
     d_s = (d_u * 100).to(torch.int16)
     ms, mn = timed(torch, lambda: fa.data2interpolation_device(d_s.data_ptr(), fa.CDM_SHORT, d_s.numel(), -32767.0, d_u.data_ptr(), st))

@@ -430,13 +430,19 @@ __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
 // Bands are pipelined over the 16 waves of the workgroup: the first lane of band b needs the last row of band b-1,
 // published through an LDS progress counter (release/acquire at workgroup scope; all waves of a workgroup share
 // the CU's L1).  One workgroup barrier per sweep remains (border pass, convergence test).
-constexpr int kV2Waves = 16;
-constexpr int kV2Threads = kV2Waves * kWave;
-constexpr int kCh = 16;            // skewed columns per chunk (16 or 32): one global-memory event per chunk
-constexpr int kRowsPerIt = kWave / kCh;      // rows one wave-wide load / store of a chunk covers
-constexpr int kChunksPerWord = 32 / kCh;     // chunks per 32-column mask word
-constexpr int kRingW = 2 * kCh;    // ring width (two chunks)
-constexpr int kPitch = kRingW + 1; // conflict-free: bank = (lane + x') mod 32
+// Two geometries are built: 16 waves on 16-column chunks (more bands in flight, the faster first-guess sums: small
+// batches and calls that leave after a few sweeps) and 8 waves on 32-column chunks (whole 128-byte row pieces per
+// memory event: large batches, where the chunk traffic of all slices meets in L2).  FILL_GEOMETRY(CH, WAVES) puts the
+// derived constants into the scope of a function template.
+#define FILL_GEOMETRY(CH, WAVES)                                                                                        \
+    constexpr int kCh = (CH);                  /* skewed columns per chunk: one global-memory event per chunk */      \
+    constexpr int kV2Waves = (WAVES);                                                                                   \
+    constexpr int kV2Threads = kV2Waves * kWave;                                                                        \
+    constexpr int kRowsPerIt = kWave / kCh;    /* rows one wave-wide load / store of a chunk covers */                \
+    constexpr int kChunksPerWord = 32 / kCh;   /* chunks per 32-column mask word */                                   \
+    constexpr int kRingW = 2 * kCh;            /* ring width (two chunks) */                                          \
+    constexpr int kPitch = kRingW + 1;         /* conflict-free: bank = (lane + x') mod 32 */                         \
+    (void)kV2Threads; (void)kRowsPerIt; (void)kChunksPerWord; (void)kRingW; (void)kPitch
 constexpr int kMaxBands = 4096;
 
 struct Fill2dV2Args {
@@ -495,9 +501,11 @@ __device__ __forceinline__ unsigned int hand_tag(uint32_t band, uint32_t cols) {
 // one band of one sweep, executed by one wave.  Global memory is touched only in the "event" between two 16-step
 // chunks: loads issued there are consumed one event later, stores are never waited for (the sweep ends with a
 // workgroup barrier); the 16 steps in between run on registers and LDS.
+template <int CH, int WAVES>
 __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ maskS, float* ring, Handoff hand, uint32_t b,
                             uint32_t nx, uint32_t ny, uint32_t mws, float wInt, float wZero, bool check, float crtest, int& bad)
 {
+    FILL_GEOMETRY(CH, WAVES);
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t y0 = 1 + kWave * b;
@@ -782,8 +790,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     if (lane == 0) lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
 }
 
-__global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
+template <int CH, int WAVES>
+__global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a)
 {
+    FILL_GEOMETRY(CH, WAVES);
     extern __shared__ __attribute__((aligned(16))) float smem[];  // rings [16][64][33] floats, hand-off [16][2][192] + counters
     __shared__ double shAverage, shCrit;
     __shared__ unsigned long long shUndef;
@@ -864,7 +874,7 @@ __global__ void __launch_bounds__(kV2Threads) fill2d_kernel_v2(Fill2dV2Args a)
         if (threadIdx.x < kV2Waves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
         __syncthreads();
         for (uint32_t b = wave; b < nBands; b += kV2Waves)
-            fill2d_band(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, check, crtest, bad);
+            fill2d_band<CH, WAVES>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, check, crtest, bad);
         if (check) {
             if (!__syncthreads_or(bad)) return;  // converged (:1355-1359), before the border pass
         } else {
@@ -1538,10 +1548,17 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         a.corrEff = corrEff;
         a.maxLoop = maxLoop;
         a.sumAlgo = tuning("SUM_ALGO", 1);
-        constexpr size_t ldsBytes = (size_t)kV2Waves * kWave * kPitch * sizeof(float) + (size_t)kV2Waves * 2 * kHandW * sizeof(float) +
-                                    (size_t)kV2Waves * 4 * sizeof(unsigned int);
-        allow_dynamic_lds(reinterpret_cast<const void*>(&fill2d_kernel_v2), ldsBytes);
-        fill2d_kernel_v2<<<dim3((uint32_t)nz), kV2Threads, ldsBytes, stream>>>(a);
+        // small batches and short calls: 16 waves x 16 columns; from FILL_WIDE_NZ slices on: 8 waves x 32 columns
+        const int geometry = tuning("FILL_GEOMETRY", 0);  // 0: by batch size, 1: 16 x 16, 2: 8 x 32
+        const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 48));
+        auto launch = [&](auto kernel, int ch, int waves) {
+            const size_t ldsBytes = (size_t)waves * kWave * (2 * ch + 1) * sizeof(float) + (size_t)waves * 2 * kHandW * sizeof(float) +
+                                    (size_t)waves * 4 * sizeof(unsigned int);
+            allow_dynamic_lds(reinterpret_cast<const void*>(kernel), ldsBytes);
+            kernel<<<dim3((uint32_t)nz), waves * kWave, ldsBytes, stream>>>(a);
+        };
+        if (wide) launch(&fill2d_kernel_v2<32, 8>, 32, 8);
+        else launch(&fill2d_kernel_v2<16, 16>, 16, 16);
         FA_HIP(hipGetLastError());
         collect_stats(stats, nz, h_nChanged, stream, "fill2d");
         return;

@@ -4,6 +4,8 @@ relative for bilinear / bicubic / rotation.  The kernels are built with -ffp-con
 follow the reference's operation order, so every comparison below is in fact bit-exact on defined
 values with identical NaN positions; the 1e-5 bound is asserted as well where north_star names it.
 """
+import functools
+
 import numpy as np
 import pytest
 
@@ -202,16 +204,35 @@ def test_vector_rotation_90_degrees(fa):
 @pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2), (4, 4, 1), (5, 70, 1), (300, 200, 2),
                                    (64, 66, 1), (33, 1200, 1), (1000, 131, 1), (5000, 1100, 1)])
 @pytest.mark.parametrize("params", [(4.0, 1.6, 100), (0.5, 1.0, 23), (4.0, 1.9, 3), (1e-9, 1.6, 41)])
-def test_fill2d_matches_oracle(fa, shape, params):
+@pytest.mark.parametrize("geometry", ["1", "2"], ids=["16waves_x_16columns", "8waves_x_32columns"])
+def test_fill2d_matches_oracle(fa, monkeypatch, shape, params, geometry):
+    """Both band geometries of the systolic kernel (the launcher picks by batch size) against the CPU restatement."""
     nx, ny, nz = shape
     relaxCrit, corrEff, maxLoop = params
+    monkeypatch.setenv("FIMEX_AMD_FILL_GEOMETRY", geometry)
     f = cases.holes(nz, ny, nx, seed=nx * 31 + ny)
     got, nch = fa.fill2d_host(f, relaxCrit, corrEff, maxLoop)
     for z in range(nz):
-        want, wn, rc = oracle.fill2d(f[z], relaxCrit, corrEff, maxLoop)
+        want, wn, rc = _oracle_fill2d(nx, ny, nz, z, relaxCrit, corrEff, maxLoop)
         assert rc == oracle.OK
         assert nch[z] == wn
         assert cases.same(got[z], want), "slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+
+
+@functools.lru_cache(maxsize=None)
+def _oracle_fill2d(nx, ny, nz, z, relaxCrit, corrEff, maxLoop):
+    return oracle.fill2d(cases.holes(nz, ny, nx, seed=nx * 31 + ny)[z], relaxCrit, corrEff, maxLoop)
+
+
+def test_fill2d_geometry_follows_the_batch_size(fa, monkeypatch):
+    """48 slices and more run the 8-wave, 32-column geometry by default; the result does not depend on it."""
+    f = np.stack([cases.holes(1, 90, 140, seed=5)[0]] * 50)
+    want, wn, rc = oracle.fill2d(f[0], 4.0, 1.6, 40)
+    got, nch = fa.fill2d_host(f, 4.0, 1.6, 40)
+    assert all(n == wn for n in nch) and all(cases.same(got[z], want) for z in range(50))
+    monkeypatch.setenv("FIMEX_AMD_FILL_GEOMETRY", "1")
+    again, _ = fa.fill2d_host(f, 4.0, 1.6, 40)
+    assert cases.same(again, got)
 
 
 @pytest.mark.parametrize("shape", [(40, 30, 3), (97, 61, 2), (2, 2, 1), (3, 17, 1), (130, 5, 2), (4, 4, 1), (5, 70, 1), (300, 200, 2),

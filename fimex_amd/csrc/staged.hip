@@ -529,7 +529,10 @@ bool try_build_staged(fimex_amd_regrid_plan& plan, const double* d_px, const dou
 bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
 {
     if (plan.inX % 4 != 0) return false;
-    const uint32_t tw = (uint32_t)tuning("STAGE_TW", 64);
+    // output columns per tile: wide tiles fetch fewer lines twice (bilinear on the benchmark plan: 14.0 / 11.7 / 10.6 GB per
+    // launch at 32 / 64 / 128 columns) but are only 1-2 % faster -- the duplicates are served by the memory-side cache;
+    // the 4x4 stencil prefers squarer tiles (fewer halo rows)
+    const uint32_t tw = (uint32_t)tuning("STAGE_TW", plan.kind == PlanKind::Bicubic ? 32 : 128);
     if (!(tw == 32 || tw == 64 || tw == 128 || tw == 256)) return false;
     const int forcedPer = tuning("STAGE_PER", 0), forcedK = tuning("STAGE_K", 0);
     if (plan.kind == PlanKind::Bilinear) {

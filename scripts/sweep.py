@@ -22,8 +22,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     wl = workloads.BilinearRotatedPole()
     method = {"bilinear": fa.BILINEAR, "bicubic": fa.BICUBIC, "nearest": fa.NEAREST_NEIGHBOR}[a.method]
-    plan, px, py = bench.build_plan(fa, torch, wl, method, stream)
-    print("plan info:", plan.info(), flush=True)
+    plans = {}
     d_in = bench.make_slices(torch, wl.base_field(), a.nz)
     d_out = torch.empty((a.nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
     keys = set()
@@ -36,6 +35,11 @@ def main():
         for kv in filter(None, v.split(",")):
             k, val = kv.split("=")
             os.environ["FIMEX_AMD_" + k] = val
+    for v in a.variants:  # tile shape knobs (STAGE_TW, STAGE_PER, STAGE_K) act when the plan is built
+        setenv(v)
+        plans[v] = bench.build_plan(fa, torch, wl, method, stream)[0]
+        info = plans[v].info()
+        print("plan %-30s tile %sx%s staged cells %s" % (v or "(defaults)", info.get("tileW"), info.get("tileH"), info.get("stagedCells")), flush=True)
     times = {v: [] for v in a.variants}
     for r in range(a.rounds + 1):
         for v in a.variants:
@@ -43,7 +47,7 @@ def main():
             for _ in range(a.reps):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                plan.apply_device(d_in.data_ptr(), a.nz, d_out.data_ptr(), stream)
+                plans[v].apply_device(d_in.data_ptr(), a.nz, d_out.data_ptr(), stream)
                 e1.record()
                 torch.cuda.synchronize()
                 if r > 0:

@@ -65,7 +65,7 @@ def test_backward_ragged_z_counts(fa, method, nz):
 
 @pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
 @pytest.mark.parametrize("shape", [(400, 300, 200, 200, 10), (1000, 700, 333, 257, 7), (128, 96, 640, 480, 3), (64, 2000, 50, 300, 5)])
-@pytest.mark.parametrize("knobs", [{"STAGED": "0"}, {"STAGED": "1"}, {"STAGED": "1", "STAGE_TW": "128"},
+@pytest.mark.parametrize("knobs", [{"STAGED": "0"}, {"STAGED": "1"}, {"STAGED": "1", "STAGE_TW": "64"},
                                    {"STAGED": "1", "STAGE_TW": "32", "STAGE_ZPB": "3"},
                                    {"STAGED": "1", "STAGE_TW": "256", "STAGE_ZPB": "1", "XCD": "1"},
                                    {"STAGED": "1", "XCD": "3", "STAGED_MIN_NZ": "1"}])

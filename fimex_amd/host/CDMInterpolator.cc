@@ -10,7 +10,7 @@ namespace FimexAmd {
 
 namespace {
 const double DEG_TO_RAD = .0174532925199432958;  // proj_api.h
-const std::string LAT_LON_PROJSTR = "+proj=latlong +R=6371000";  // sphere stand-in for MIFI_WGS84_LATLON_PROJ4 (no datum shift either way)
+const std::string LAT_LON_PROJSTR = "+proj=latlong +datum=WGS84 +towgs84=0,0,0 +no_defs";  // MIFI_WGS84_LATLON_PROJ4, mifi_constants.h
 
 bool isDegreeUnit(const std::string& unit) { return unit.find("degree") != std::string::npos; }  // boost::regex(".*degree.*")
 
@@ -108,6 +108,89 @@ void CDMInterpolator::changeProjectionByProjectionParameters(int method, const s
     std::copy(matrix_.begin(), matrix_.end(), m.get());
     cachedVectorReprojection_ =
         std::make_shared<CachedVectorReprojection>(MIFI_VECTOR_KEEP_SIZE, m, (int)outXAxis.size(), (int)outYAxis.size());
+}
+
+// src/CDMInterpolator.cc:460-510
+void CDMInterpolator::changeProjection(int method, const std::vector<double>& lonVals, const std::vector<double>& latVals)
+{
+    if (lonVals.size() != latVals.size()) {  // :465-469: logged, nothing changes
+        std::cerr << "changeProjection, number of longitude and latitude values differs: " << lonVals.size() << " != " << latVals.size() << std::endl;
+        return;
+    }
+    switch (method) {
+    case MIFI_INTERPOL_NEAREST_NEIGHBOR:
+    case MIFI_INTERPOL_BILINEAR:
+    case MIFI_INTERPOL_BICUBIC: {
+        // the reference passes the values on as float Data (:475-481)
+        std::vector<float> tmplLat(latVals.begin(), latVals.end()), tmplLon(lonVals.begin(), lonVals.end());
+        changeProjectionByProjectionParametersToLatLonTemplate(method, LAT_LON_PROJSTR, lonVals.size(), 1, tmplLat, tmplLon);
+        break;
+    }
+    case MIFI_INTERPOL_COORD_NN: case MIFI_INTERPOL_COORD_NN_KD: case MIFI_INTERPOL_FORWARD_SUM: case MIFI_INTERPOL_FORWARD_MEAN:
+    case MIFI_INTERPOL_FORWARD_MEDIAN: case MIFI_INTERPOL_FORWARD_MAX: case MIFI_INTERPOL_FORWARD_MIN:
+        throw CDMException("projection method: " + std::to_string(method) + ", not supported");
+    default:
+        throw CDMException("unknown projection method: " + std::to_string(method));
+    }
+}
+
+// src/CDMInterpolator.cc:651-712: only the three backward methods (:697-708)
+void CDMInterpolator::changeProjectionToTemplate(int method, const std::vector<float>& tmplLonVals, const std::vector<float>& tmplLatVals,
+                                                 size_t outX, size_t outY)
+{
+    if (tmplLonVals.size() != outX * outY || tmplLatVals.size() != outX * outY)
+        throw CDMException("template longitude / latitude do not have outX * outY values");
+    switch (method) {
+    case MIFI_INTERPOL_NEAREST_NEIGHBOR:
+    case MIFI_INTERPOL_BILINEAR:
+    case MIFI_INTERPOL_BICUBIC:
+        changeProjectionByProjectionParametersToLatLonTemplate(method, LAT_LON_PROJSTR, outX, outY, tmplLatVals, tmplLonVals);
+        break;
+    default:
+        throw CDMException("unknown projection method: " + std::to_string(method));
+    }
+}
+
+// src/CDMInterpolator.cc:1706-1820
+void CDMInterpolator::changeProjectionByProjectionParametersToLatLonTemplate(int method, const std::string& tmpl_proj_input, size_t outX,
+                                                                             size_t outY, const std::vector<float>& tmplLatVals,
+                                                                             const std::vector<float>& tmplLonVals)
+{
+    const std::string orgProjStr = dataReader_->projString();
+    const size_t n = tmplLatVals.size();
+    // template data is in degrees (:1761-1766)
+    std::vector<double> latY(tmplLatVals.begin(), tmplLatVals.end()), lonX(tmplLonVals.begin(), tmplLonVals.end());
+    toRad(latY);
+    toRad(lonX);
+    const std::vector<double> latRad = latY, lonRad = lonX;
+    // template lat / lon expressed in the original projection (:1773), then on the original axes (:1792-1793)
+    checkAmd(fimex_amd_project_values_host(tmpl_proj_input.c_str(), orgProjStr.c_str(), lonX.data(), latY.data(), n),
+             ("unable to project values from " + orgProjStr + " to " + tmpl_proj_input).c_str());
+    std::vector<double> orgX = dataReader_->xAxis(), orgY = dataReader_->yAxis();
+    int miupXAxis = MIFI_PROJ_AXIS, miupYAxis = MIFI_PROJ_AXIS;
+    const bool degree = isDegreeProjection(orgProjStr);
+    if (degree) {
+        miupXAxis = MIFI_LONGITUDE;
+        miupYAxis = MIFI_LATITUDE;
+        toRad(orgX);
+        toRad(orgY);
+    }
+    points2position(latY, orgY, miupYAxis);
+    points2position(lonX, orgX, miupXAxis);
+    pointsOnXAxis_ = lonX;
+    pointsOnYAxis_ = latY;
+    auto ci = std::make_shared<CachedInterpolation>(dataReader_->xDimName(), dataReader_->yDimName(), method, pointsOnXAxis_,
+                                                    pointsOnYAxis_, orgX.size(), orgY.size(), outX, outY);
+    ci->createReducedDomain(dataReader_->xDimName(), dataReader_->yDimName());  // :1802
+    cachedInterpolation_ = ci;
+    // rotation of x/y vectors to east / north at every template point (:1808-1824)
+    matrix_.resize(4 * n);
+    checkAmd(fimex_amd_get_vector_reproject_matrix_points_host(orgProjStr.c_str(), LAT_LON_PROJSTR.c_str(), degree ? 0 : 1, lonRad.data(),
+                                                               latRad.data(), n, matrix_.data()),
+             "mifi_get_vector_reproject_matrix_points");
+    shared_array<double> m(new double[matrix_.size()]);
+    std::copy(matrix_.begin(), matrix_.end(), m.get());
+    cachedVectorReprojection_ = std::make_shared<CachedVectorReprojection>(MIFI_VECTOR_KEEP_SIZE, m, (int)n, 1);
 }
 
 // src/CDMInterpolator.cc:304-326

@@ -65,6 +65,14 @@ public:
                           const std::vector<double>& out_y_axis, const std::string& out_x_axis_unit,
                           const std::string& out_y_axis_unit);
 
+    // include/fimex/CDMInterpolator.h:228 (src/CDMInterpolator.cc:460-510): the target is a list of longitude / latitude
+    // points in degrees (nearest, bilinear, bicubic only); output grid x = 0 .. n-1, y = 0
+    void changeProjection(int method, const std::vector<double>& lonVals, const std::vector<double>& latVals);
+    // include/fimex/CDMInterpolator.h:204-219 (src/CDMInterpolator.cc:651-712) reduced to what the path needs from the
+    // template reader: the 2-D longitude / latitude (degrees, [outY][outX]) of the template's grid
+    void changeProjectionToTemplate(int method, const std::vector<float>& tmplLonVals, const std::vector<float>& tmplLatVals, size_t outX,
+                                    size_t outY);
+
     // src/CDMInterpolator.cc:235-287; returns [levels][outY][outX] floats with the variable's fill value restored
     shared_array<float> getDataSlice(const std::string& varName, size_t unLimDimPos, size_t& size);
     // the same on the variable's stored type, as the reference's DataPtr-returning getDataSlice: data2InterpolationArray
@@ -95,6 +103,9 @@ private:
 
     void changeProjectionByProjectionParameters(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                 std::vector<double> outYAxis, bool xDegree, bool yDegree);
+    void changeProjectionByProjectionParametersToLatLonTemplate(int method, const std::string& tmpl_proj_input, size_t outX, size_t outY,
+                                                                const std::vector<float>& tmplLatVals,
+                                                                const std::vector<float>& tmplLonVals);
     void changeProjectionByCoordinates(int method, const std::string& proj_input, const std::vector<double>& out_x_axis,
                                        const std::vector<double>& out_y_axis, bool xDegree, bool yDegree);
     void changeProjectionByForwardInterpolation(int method, const std::string& proj_input, std::vector<double> outXAxis,

@@ -10,6 +10,8 @@
 //   method <name>                 outproj <proj4>
 //   lon2d|lat2d <file of doubles [ny][nx], degrees>   (coord_nearestneighbor / coord_kdtree / forward_*)   maxdist <metres>
 //   outx <file of doubles> <unit> outy <file of doubles> <unit>
+//   points <file of lon doubles> <file of lat doubles>            (changeProjection(method, lonVals, latVals) instead of outx / outy)
+//   template <file of lon floats> <file of lat floats> <nx> <ny>  (changeProjectionToTemplate)
 //   pre|post fill2d <relaxCrit> <corrEff> <maxLoop> | creepfill2d <repeat> <weight> | creepfillval2d <repeat> <weight> <default>
 //   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32 for float variables, .raw in the stored type otherwise)
 // Also writes <out_dir>/points_x.f64, points_y.f64 (plan positions) and matrix.f64 (rotation matrix, if any).
@@ -136,7 +138,10 @@ int main(int argc, char** argv)
         std::ifstream spec(argv[1]);
         const std::string outDir = argv[2];
         std::string line, method, outproj, outxUnit, outyUnit;
-        std::vector<double> outx, outy;
+        std::vector<double> outx, outy, pointLon, pointLat;
+        std::vector<float> tmplLon, tmplLat;
+        size_t tmplNx = 0, tmplNy = 0;
+        bool usePoints = false, useTemplate = false;
         double maxDist = -1;
         std::vector<std::pair<std::string, size_t>> gets;
         std::vector<std::pair<bool, std::shared_ptr<InterpolatorProcess2d>>> procs;
@@ -153,6 +158,8 @@ int main(int argc, char** argv)
             else if (key == "maxdist") { in >> maxDist; }
             else if (key == "outx") { std::string f; in >> f >> outxUnit; outx = readAll<double>(f); }
             else if (key == "outy") { std::string f; in >> f >> outyUnit; outy = readAll<double>(f); }
+            else if (key == "points") { std::string a, b; in >> a >> b; pointLon = readAll<double>(a); pointLat = readAll<double>(b); usePoints = true; }
+            else if (key == "template") { std::string a, b; in >> a >> b >> tmplNx >> tmplNy; tmplLon = readAll<float>(a); tmplLat = readAll<float>(b); useTemplate = true; }
             else if (key == "method") { in >> method; }
             else if (key == "var") {
                 VariableInfo v;
@@ -190,7 +197,9 @@ int main(int argc, char** argv)
         const int m = mifi_string_to_interpolation_method(method.c_str());
         if (m == MIFI_INTERPOL_UNKNOWN) throw CDMException("unknown method " + method);
         interp.setDistanceOfInterest(maxDist);
-        interp.changeProjection(m, outproj, outx, outy, outxUnit, outyUnit);
+        if (usePoints) interp.changeProjection(m, pointLon, pointLat);
+        else if (useTemplate) interp.changeProjectionToTemplate(m, tmplLon, tmplLat, tmplNx, tmplNy);
+        else interp.changeProjection(m, outproj, outx, outy, outxUnit, outyUnit);
         writeAll(outDir + "/points_x.f64", interp.pointsOnXAxis().data(), interp.pointsOnXAxis().size());
         writeAll(outDir + "/points_y.f64", interp.pointsOnYAxis().data(), interp.pointsOnYAxis().size());
         writeAll(outDir + "/matrix.f64", interp.rotationMatrix().data(), interp.rotationMatrix().size());

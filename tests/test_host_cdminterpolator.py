@@ -237,3 +237,73 @@ def test_coordtest_by_its_stored_coordinates(tmp_path, golden_dir, method, code,
     got = np.fromfile(out / "air_temperature_3.raw", dtype=np.int16).reshape(want.shape)
     assert np.array_equal(got, want)
     assert set(np.unique(got)) <= set(np.unique(t[3])) | {-32767}  # nearest neighbour: only values of the source
+
+
+@pytest.mark.parametrize("method,code", [("bilinear", oracle.BILINEAR), ("nearestneighbor", oracle.NEAREST), ("bicubic", oracle.BICUBIC)])
+def test_coordtest_to_a_list_of_points(tmp_path, coordtest, method, code):
+    """changeProjection(method, lonVals, latVals) (src/CDMInterpolator.cc:460-510 -> :1706-1824): the target is a list of
+    stations; the values travel as float, the plan is outX = n, outY = 1, x/y winds are turned to east / north with
+    mifi_get_vector_reproject_matrix_points."""
+    ct = coordtest
+    rng = np.random.default_rng(12)
+    lon, lat = rng.uniform(-15.0, -9.9, 57), rng.uniform(28.5, 32.8, 57)
+    lon[:3], lat[:3] = (-40., 0., 170.), (10., 89., -30.)   # far outside the 11x11 grid
+    lon.tofile(tmp_path / "plon.f64"); lat.tofile(tmp_path / "plat.f64")
+    lines, _, _ = _spec_common(tmp_path, ct, method, ["points %s %s" % (tmp_path / "plon.f64", tmp_path / "plat.f64"),
+                                                     "get air_temperature 1", "get x_wind_10m 0", "get y_wind_10m 0"])
+    out, stdout = _run(tmp_path, lines)
+    assert "outX 57 outY 1" in stdout
+    lonf, latf = lon.astype(np.float32).astype(np.float64), lat.astype(np.float32).astype(np.float64)
+    geo = "+proj=latlong +datum=WGS84 +towgs84=0,0,0 +no_defs"
+    wx, wy = po.transform(geo, ct["proj"], np.radians(lonf), np.radians(latf))
+    wx, wy = oracle.points2position(wx, ct["x"]), oracle.points2position(wy, ct["y"])
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    np.testing.assert_allclose(px, wx, atol=1e-7); np.testing.assert_allclose(py, wy, atol=1e-7)
+
+    def regrid(name, step):
+        fill = FILL_FLOAT if ct[name + "_fill"] is None else float(ct[name + "_fill"])
+        return oracle.interpolate_values(code, px, py, oracle.bad2nan(ct[name][step], fill), 11, 11, 57, 1), fill
+
+    got = np.fromfile(out / "air_temperature_1.f32", dtype=np.float32).reshape(-1, 1, 57)
+    want, fill = regrid("air_temperature", 1)
+    want = oracle.interpolation_array2data(want, oracle.CDM_FLOAT, fill)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert (got[:, 0, :3] == np.float32(fill)).all() and (got[:, 0, 3:] != np.float32(fill)).any()
+    # winds: the matrix at the points against the restatement, the data through the matrix the host built
+    m = np.fromfile(out / "matrix.f64")
+    ix, iy = po.transform(geo, ct["proj"], np.radians(lonf), np.radians(latf))
+    xdx = po.transform(ct["proj"], geo, ix + 100, iy)
+    ydy = po.transform(ct["proj"], geo, ix, iy + 100)
+    wm = oracle.vector_matrix_from_deltas(np.radians(lonf), np.radians(latf), xdx, ydy, 100., 100., True).reshape(-1, 4)
+    np.testing.assert_allclose(m.reshape(-1, 4)[3:, :3], wm[3:, :3], atol=1e-6)
+    (u, fu), (v, fv) = regrid("x_wind_10m", 0), regrid("y_wind_10m", 0)
+    ru, rv = oracle.vector_reproject_values(m, u, v, 57, 1)
+    gu = np.fromfile(out / "x_wind_10m_0.f32", dtype=np.float32).reshape(-1, 1, 57)
+    gv = np.fromfile(out / "y_wind_10m_0.f32", dtype=np.float32).reshape(-1, 1, 57)
+    assert cases.same(gu, oracle.interpolation_array2data(ru, oracle.CDM_FLOAT, fu))
+    assert cases.same(gv, oracle.interpolation_array2data(rv, oracle.CDM_FLOAT, fv))
+
+
+def test_coordtest_to_a_template_grid(tmp_path, coordtest):
+    """changeProjection(method, template) (src/CDMInterpolator.cc:651-712 -> :1706-1824): the target grid is given by the 2-D
+    longitude / latitude of a template file -- here a curvilinear 40 x 25 mesh."""
+    ct = coordtest
+    jj, ii = np.meshgrid(np.arange(25), np.arange(40), indexing="ij")
+    lon2 = (-14.6 + 0.11 * ii + 0.02 * jj + 0.3 * np.sin(jj / 6.0)).astype(np.float32)
+    lat2 = (28.9 + 0.14 * jj - 0.015 * ii + 0.2 * np.cos(ii / 9.0)).astype(np.float32)
+    lon2.tofile(tmp_path / "tlon.f32"); lat2.tofile(tmp_path / "tlat.f32")
+    lines, _, _ = _spec_common(tmp_path, ct, "bilinear", ["template %s %s 40 25" % (tmp_path / "tlon.f32", tmp_path / "tlat.f32"),
+                                                         "get air_temperature 2"])
+    out, stdout = _run(tmp_path, lines)
+    assert "outX 40 outY 25" in stdout
+    geo = "+proj=latlong +datum=WGS84 +towgs84=0,0,0 +no_defs"
+    wx, wy = po.transform(geo, ct["proj"], np.radians(lon2.astype(np.float64).ravel()), np.radians(lat2.astype(np.float64).ravel()))
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    np.testing.assert_allclose(px, oracle.points2position(wx, ct["x"]), atol=1e-7)
+    np.testing.assert_allclose(py, oracle.points2position(wy, ct["y"]), atol=1e-7)
+    fill = FILL_FLOAT if ct["air_temperature_fill"] is None else float(ct["air_temperature_fill"])
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, oracle.bad2nan(ct["air_temperature"][2], fill), 11, 11, 40, 25)
+    want = oracle.interpolation_array2data(want, oracle.CDM_FLOAT, fill)
+    got = np.fromfile(out / "air_temperature_2.f32", dtype=np.float32).reshape(-1, 25, 40)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.fromfile(out / "matrix.f64").size == 4 * 40 * 25

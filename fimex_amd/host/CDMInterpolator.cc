@@ -4,6 +4,7 @@
 #include <cmath>
 #include <iostream>
 #include <limits>
+#include <sstream>
 #include <string>
 
 namespace FimexAmd {
@@ -34,6 +35,53 @@ bool isDegreeProjection(const std::string& proj)
     const int r = fimex_amd_projection_is_degree(proj.c_str());
     if (r < 0) throw CDMException(std::string("projection: ") + fimex_amd_last_error());
     return r != 0;
+}
+
+const double RAD_TO_DEG = 57.29577951308232;  // proj_api.h
+
+// Projection::getProj4EarthString: the figure-of-the-earth parameters of a proj4 string
+std::string proj4EarthString(const std::string& proj)
+{
+    std::istringstream in(proj);
+    std::string tok, earth;
+    while (in >> tok) {
+        const std::string key = tok.substr(0, tok.find('='));
+        for (const char* k : {"+a", "+b", "+e", "+es", "+f", "+rf", "+R", "+ellps", "+datum", "+towgs84"})
+            if (key == k) earth += (earth.empty() ? "" : " ") + tok;
+    }
+    return earth;
+}
+
+// Projection::convertFromLonLat / convertToLonLat (src/coordSys/Projection.cc:74-140): degrees in, the grid's own unit out
+// (degrees for geographic and rotated grids, metres otherwise) and back
+void convertFromLonLat(const std::string& proj, std::vector<double>& x, std::vector<double>& y)
+{
+    if (x.empty()) return;
+    toRad(x);
+    toRad(y);
+    const std::string fromProj = "+proj=latlong " + proj4EarthString(proj);
+    if (fromProj == proj) return;  // as the reference (:130): the values stay in radians
+    checkAmd(fimex_amd_project_values_host(fromProj.c_str(), proj.c_str(), x.data(), y.data(), x.size()),
+             ("convertFromLonLat: unable to convert from '" + fromProj + "' to '" + proj + "'").c_str());
+    if (isDegreeProjection(proj)) {
+        for (double& v : x) v *= RAD_TO_DEG;
+        for (double& v : y) v *= RAD_TO_DEG;
+    }
+}
+
+void convertToLonLat(const std::string& proj, std::vector<double>& x, std::vector<double>& y)
+{
+    if (x.empty()) return;
+    if (isDegreeProjection(proj)) {
+        toRad(x);
+        toRad(y);
+    }
+    const std::string toProj = "+proj=latlong " + proj4EarthString(proj);
+    if (proj == toProj) return;
+    checkAmd(fimex_amd_project_values_host(proj.c_str(), toProj.c_str(), x.data(), y.data(), x.size()),
+             ("convertToLonLat: unable to convert from '" + proj + "' to '" + toProj + "'").c_str());
+    for (double& v : x) v *= RAD_TO_DEG;
+    for (double& v : y) v *= RAD_TO_DEG;
 }
 
 void points2position(std::vector<double>& points, const std::vector<double>& axis, int axisType)
@@ -132,6 +180,65 @@ void CDMInterpolator::changeProjection(int method, const std::vector<double>& lo
     default:
         throw CDMException("unknown projection method: " + std::to_string(method));
     }
+}
+
+// src/CDMInterpolator.cc:512-633
+void CDMInterpolator::changeProjectionToCrossSections(int method, const std::vector<CrossSectionDefinition>& crossSections)
+{
+    const std::string proj = dataReader_->projString();
+    const std::vector<double> xAxis = dataReader_->xAxis(), yAxis = dataReader_->yAxis();  // degrees or metres, as the grid has them
+    if (xAxis.size() < 2 || yAxis.size() < 2) throw CDMException("x- or y-axis sizes < 2 elements, not possible to interpolate");
+    const double dx = xAxis[1] - xAxis[0], dy = yAxis[1] - yAxis[0];
+    if (dx == 0 || dy == 0) throw CDMException("cross-section calculation: dx or dy derived from first two elements == 0");
+
+    std::vector<double> lonVals, latVals;
+    std::vector<size_t> startPositions;
+    std::vector<std::string> names;
+    for (const CrossSectionDefinition& cs : crossSections) {
+        if (cs.lonLatCoordinates.empty()) continue;
+        names.push_back(cs.name);
+        startPositions.push_back(lonVals.size());
+        if (cs.lonLatCoordinates.size() == 1) {
+            lonVals.push_back(cs.lonLatCoordinates[0].first);
+            latVals.push_back(cs.lonLatCoordinates[0].second);
+            continue;
+        }
+        for (size_t i = 1; i < cs.lonLatCoordinates.size(); ++i) {
+            std::vector<double> xLon = {cs.lonLatCoordinates[i - 1].first, cs.lonLatCoordinates[i].first};
+            std::vector<double> yLat = {cs.lonLatCoordinates[i - 1].second, cs.lonLatCoordinates[i].second};
+            convertFromLonLat(proj, xLon, yLat);
+            const double xLonD = xLon[1] - xLon[0], yLatD = yLat[1] - yLat[0];
+            // number of grid points between two waypoints (:565)
+            const size_t num = static_cast<size_t>(std::floor(std::max(std::fabs(xLonD / dx), std::fabs(yLatD / dy))));
+            std::vector<double> xLonPart, yLatPart;
+            if (i == 1) {  // the first waypoint belongs to the first leg only
+                xLonPart.push_back(xLon[0]);
+                yLatPart.push_back(yLat[0]);
+            }
+            for (size_t j = 1; j < num; ++j) {
+                xLonPart.push_back(xLon[0] + j * xLonD / num);
+                yLatPart.push_back(yLat[0] + j * yLatD / num);
+            }
+            xLonPart.push_back(xLon[1]);
+            yLatPart.push_back(yLat[1]);
+            convertToLonLat(proj, xLonPart, yLatPart);
+            lonVals.insert(lonVals.end(), xLonPart.begin(), xLonPart.end());
+            latVals.insert(latVals.end(), yLatPart.begin(), yLatPart.end());
+        }
+    }
+    if (names.empty()) throw CDMException("no cross-section with coordinates");
+    // vcross_name / vcross_bnds (:587-626)
+    csNames_ = names;
+    csBounds_.assign(2 * names.size(), 0);
+    for (size_t i = 0; i + 1 < names.size(); ++i) {
+        csBounds_[2 * i] = (int)startPositions[i];
+        csBounds_[2 * i + 1] = (int)startPositions[i + 1] - 1;
+    }
+    csBounds_[2 * (names.size() - 1)] = (int)startPositions.back();
+    csBounds_[2 * (names.size() - 1) + 1] = (int)lonVals.size() - 1;
+    targetLon_ = lonVals;
+    targetLat_ = latVals;
+    changeProjection(method, lonVals, latVals);  // :632
 }
 
 // src/CDMInterpolator.cc:651-712: only the three backward methods (:697-708)

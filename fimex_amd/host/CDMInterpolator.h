@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "CachedInterpolation.h"
@@ -55,6 +56,13 @@ public:
     virtual bool lonLat(std::vector<double>& lon, std::vector<double>& lat) const { (void)lon; (void)lat; return false; }
 };
 
+// include/fimex/CrossSectionDefinition.h: a named polyline of (longitude, latitude) waypoints in degrees
+struct CrossSectionDefinition {
+    std::string name;
+    std::vector<std::pair<double, double>> lonLatCoordinates;
+    CrossSectionDefinition(std::string n, std::vector<std::pair<double, double>> c) : name(std::move(n)), lonLatCoordinates(std::move(c)) {}
+};
+
 class CDMInterpolator {
 public:
     explicit CDMInterpolator(std::shared_ptr<GridReader> dataReader);
@@ -72,6 +80,15 @@ public:
     // template reader: the 2-D longitude / latitude (degrees, [outY][outX]) of the template's grid
     void changeProjectionToTemplate(int method, const std::vector<float>& tmplLonVals, const std::vector<float>& tmplLatVals, size_t outX,
                                     size_t outY);
+
+    // include/fimex/CDMInterpolator.h:242 (src/CDMInterpolator.cc:512-633): points along straight lines in the source
+    // projection between the waypoints, one per source cell step, then changeProjection(method, lonVals, latVals);
+    // crossSectionNames / crossSectionBounds are the vcross_name / vcross_bnds variables the reference adds to the CDM
+    void changeProjectionToCrossSections(int method, const std::vector<CrossSectionDefinition>& crossSections);
+    const std::vector<std::string>& crossSectionNames() const { return csNames_; }
+    const std::vector<int>& crossSectionBounds() const { return csBounds_; }  // [nvcross][2]: first and last point, inclusive
+    const std::vector<double>& targetLongitudes() const { return targetLon_; }
+    const std::vector<double>& targetLatitudes() const { return targetLat_; }
 
     // src/CDMInterpolator.cc:235-287; returns [levels][outY][outX] floats with the variable's fill value restored
     shared_array<float> getDataSlice(const std::string& varName, size_t unLimDimPos, size_t& size);
@@ -100,6 +117,9 @@ private:
     std::shared_ptr<CachedVectorReprojection> cachedVectorReprojection_;
     std::vector<double> pointsOnXAxis_, pointsOnYAxis_, matrix_;
     double maxDistance_ = -1;  // src/CDMInterpolator.cc:103
+    std::vector<std::string> csNames_;
+    std::vector<int> csBounds_;
+    std::vector<double> targetLon_, targetLat_;
 
     void changeProjectionByProjectionParameters(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                 std::vector<double> outYAxis, bool xDegree, bool yDegree);

@@ -11,6 +11,8 @@
 //   lon2d|lat2d <file of doubles [ny][nx], degrees>   (coord_nearestneighbor / coord_kdtree / forward_*)   maxdist <metres>
 //   outx <file of doubles> <unit> outy <file of doubles> <unit>
 //   points <file of lon doubles> <file of lat doubles>            (changeProjection(method, lonVals, latVals) instead of outx / outy)
+//   crosssection <name> <lon> <lat> [<lon> <lat> ...]            (repeatable; changeProjectionToCrossSections; also writes
+//       vcross_bnds.i32, target_lon.f64, target_lat.f64 and prints "vcross <names...>")
 //   template <file of lon floats> <file of lat floats> <nx> <ny>  (changeProjectionToTemplate)
 //   pre|post fill2d <relaxCrit> <corrEff> <maxLoop> | creepfill2d <repeat> <weight> | creepfillval2d <repeat> <weight> <default>
 //   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32 for float variables, .raw in the stored type otherwise)
@@ -142,6 +144,7 @@ int main(int argc, char** argv)
         std::vector<float> tmplLon, tmplLat;
         size_t tmplNx = 0, tmplNy = 0;
         bool usePoints = false, useTemplate = false;
+        std::vector<CrossSectionDefinition> crossSections;
         double maxDist = -1;
         std::vector<std::pair<std::string, size_t>> gets;
         std::vector<std::pair<bool, std::shared_ptr<InterpolatorProcess2d>>> procs;
@@ -160,6 +163,14 @@ int main(int argc, char** argv)
             else if (key == "outy") { std::string f; in >> f >> outyUnit; outy = readAll<double>(f); }
             else if (key == "points") { std::string a, b; in >> a >> b; pointLon = readAll<double>(a); pointLat = readAll<double>(b); usePoints = true; }
             else if (key == "template") { std::string a, b; in >> a >> b >> tmplNx >> tmplNy; tmplLon = readAll<float>(a); tmplLat = readAll<float>(b); useTemplate = true; }
+            else if (key == "crosssection") {
+                std::string name;
+                in >> name;
+                std::vector<std::pair<double, double>> pts;
+                double lo, la;
+                while (in >> lo >> la) pts.push_back({lo, la});
+                crossSections.push_back(CrossSectionDefinition(name, pts));
+            }
             else if (key == "method") { in >> method; }
             else if (key == "var") {
                 VariableInfo v;
@@ -197,7 +208,15 @@ int main(int argc, char** argv)
         const int m = mifi_string_to_interpolation_method(method.c_str());
         if (m == MIFI_INTERPOL_UNKNOWN) throw CDMException("unknown method " + method);
         interp.setDistanceOfInterest(maxDist);
-        if (usePoints) interp.changeProjection(m, pointLon, pointLat);
+        if (!crossSections.empty()) {
+            interp.changeProjectionToCrossSections(m, crossSections);
+            writeAll(outDir + "/vcross_bnds.i32", interp.crossSectionBounds().data(), interp.crossSectionBounds().size());
+            writeAll(outDir + "/target_lon.f64", interp.targetLongitudes().data(), interp.targetLongitudes().size());
+            writeAll(outDir + "/target_lat.f64", interp.targetLatitudes().data(), interp.targetLatitudes().size());
+            std::cout << "vcross";
+            for (const std::string& n : interp.crossSectionNames()) std::cout << " " << n;
+            std::cout << std::endl;
+        } else if (usePoints) interp.changeProjection(m, pointLon, pointLat);
         else if (useTemplate) interp.changeProjectionToTemplate(m, tmplLon, tmplLat, tmplNx, tmplNy);
         else interp.changeProjection(m, outproj, outx, outy, outxUnit, outyUnit);
         writeAll(outDir + "/points_x.f64", interp.pointsOnXAxis().data(), interp.pointsOnXAxis().size());

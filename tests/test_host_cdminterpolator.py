@@ -307,3 +307,56 @@ def test_coordtest_to_a_template_grid(tmp_path, coordtest):
     got = np.fromfile(out / "air_temperature_2.f32", dtype=np.float32).reshape(-1, 25, 40)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
     assert np.fromfile(out / "matrix.f64").size == 4 * 40 * 25
+
+
+def _earth(proj):
+    return " ".join(t for t in proj.split() if t.split("=")[0] in ("+a", "+b", "+e", "+es", "+f", "+rf", "+R", "+ellps", "+datum", "+towgs84"))
+
+
+def _cross_section_points(ct, sections):
+    """numpy restatement of src/CDMInterpolator.cc:512-585 with the oracle's projection code."""
+    geo = "+proj=latlong " + _earth(ct["proj"])
+    dx, dy = ct["x"][1] - ct["x"][0], ct["y"][1] - ct["y"][0]
+    lons, lats, starts = [], [], []
+    for pts in sections:
+        starts.append(len(lons))
+        if len(pts) == 1:
+            lons.append(pts[0][0]); lats.append(pts[0][1])
+            continue
+        for i in range(1, len(pts)):
+            x, y = po.transform(geo, ct["proj"], np.radians([pts[i - 1][0], pts[i][0]]), np.radians([pts[i - 1][1], pts[i][1]]))
+            xd, yd = x[1] - x[0], y[1] - y[0]
+            num = int(np.floor(max(abs(xd / dx), abs(yd / dy))))
+            xs = ([x[0]] if i == 1 else []) + [x[0] + j * xd / num for j in range(1, num)] + [x[1]]
+            ys = ([y[0]] if i == 1 else []) + [y[0] + j * yd / num for j in range(1, num)] + [y[1]]
+            lo, la = po.transform(ct["proj"], geo, np.array(xs), np.array(ys))
+            lons += list(np.degrees(lo)); lats += list(np.degrees(la))
+    return np.array(lons), np.array(lats), starts
+
+
+def test_coordtest_cross_sections(tmp_path, coordtest):
+    """changeProjectionToCrossSections (src/CDMInterpolator.cc:512-633; test/testInterpolator.cc:474-497 checks two named
+    sections and more than five points): waypoints joined by straight lines in the grid's projection, one point per
+    grid step, then the point-list plan."""
+    ct = coordtest
+    sections = [[(-14.2, 29.1), (-12.0, 30.6), (-10.4, 32.3)], [(-13.0, 31.9)], [(-11.1, 29.0), (-14.0, 32.0)]]
+    extra = ["crosssection %s %s" % (n, " ".join("%r %r" % p for p in pts)) for n, pts in zip(("ABC", "single", "back"), sections)]
+    lines, _, _ = _spec_common(tmp_path, ct, "bilinear", extra + ["get air_temperature 0"])
+    out, stdout = _run(tmp_path, lines)
+    assert "vcross ABC single back" in stdout
+    wlon, wlat, starts = _cross_section_points(ct, sections)
+    glon, glat = np.fromfile(out / "target_lon.f64"), np.fromfile(out / "target_lat.f64")
+    assert glon.size == wlon.size > 5
+    np.testing.assert_allclose(glon, wlon, atol=1e-9); np.testing.assert_allclose(glat, wlat, atol=1e-9)
+    bnds = np.fromfile(out / "vcross_bnds.i32", dtype=np.int32).reshape(-1, 2)
+    assert bnds[:, 0].tolist() == starts and bnds[:, 1].tolist() == [s - 1 for s in starts[1:]] + [wlon.size - 1]
+    assert bnds[1, 0] == bnds[1, 1]   # the single-point section
+    assert "outX %d outY 1" % wlon.size in stdout
+    # waypoints themselves are part of the list
+    assert abs(glon[0] + 14.2) < 1e-9 and abs(glat[bnds[0, 1]] - 32.3) < 1e-9 and abs(glon[bnds[1, 0]] + 13.0) < 1e-12
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    fill = FILL_FLOAT if ct["air_temperature_fill"] is None else float(ct["air_temperature_fill"])
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, oracle.bad2nan(ct["air_temperature"][0], fill), 11, 11, wlon.size, 1)
+    want = oracle.interpolation_array2data(want, oracle.CDM_FLOAT, fill)
+    got = np.fromfile(out / "air_temperature_0.f32", dtype=np.float32).reshape(-1, 1, wlon.size)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)

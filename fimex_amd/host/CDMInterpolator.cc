@@ -440,23 +440,64 @@ TypedData GridReader::getTypedDataSlice(const std::string& varName, size_t unLim
     return d;
 }
 
-TypedData CDMInterpolator::readTypedInput(const std::string& varName, size_t unLimDimPos) const
+TypedData CDMInterpolator::readTypedInput(const std::string& varName, size_t unLimDimPos, size_t levelStart, size_t levelSize) const
 {
     const auto rd = cachedInterpolation_->reducedDomain();
     const size_t x0 = rd ? rd->xMin : 0, y0 = rd ? rd->yMin : 0;
     TypedData d = dataReader_->getTypedDataSlice(varName, unLimDimPos, x0, cachedInterpolation_->getInX(), y0, cachedInterpolation_->getInY());
     if (d.dataType != dataReader_->variable(varName).dataType)
         throw CDMException("reader delivered " + varName + " in type " + std::to_string(d.dataType));
-    return d;
+    const size_t layer = cachedInterpolation_->getInX() * cachedInterpolation_->getInY();
+    const size_t levels = layer ? d.size / layer : 0;
+    if (levelStart == 0 && (levelSize == SliceBuilder::npos || levelSize == levels)) return d;
+    // the SliceBuilder's level range (the reference's reader slices while reading, src/CachedInterpolation.cc:67-90)
+    if (levelStart > levels || (levelSize != SliceBuilder::npos && levelStart + levelSize > levels))
+        throw CDMException("slice of " + varName + " exceeds its " + std::to_string(levels) + " levels");
+    const size_t n = (levelSize == SliceBuilder::npos ? levels - levelStart : levelSize) * layer, elem = sizeOfDataType(d.dataType);
+    TypedData part;
+    part.dataType = d.dataType;
+    part.size = n;
+    part.bytes = shared_array<unsigned char>(new unsigned char[n ? n * elem : 1]);
+    std::copy(d.bytes.get() + levelStart * layer * elem, d.bytes.get() + levelStart * layer * elem + n * elem, part.bytes.get());
+    return part;
 }
 
 // src/CDMInterpolator.cc:235-287
 TypedData CDMInterpolator::getTypedDataSlice(const std::string& varName, size_t unLimDimPos)
 {
+    return regridLevels(varName, unLimDimPos, 0, SliceBuilder::npos);
+}
+
+// src/CDMInterpolator.cc:162-233
+TypedData CDMInterpolator::getTypedDataSlice(const std::string& varName, const SliceBuilder& sb)
+{
+    TypedData full = regridLevels(varName, sb.unLimDimPos, sb.levelStart, sb.levelSize);
+    if (full.size == 0) return full;  // :189-190
+    const size_t outX = cachedInterpolation_->getOutX(), outY = cachedInterpolation_->getOutY();
+    const size_t nx = sb.xSize == SliceBuilder::npos ? outX - std::min(outX, sb.xStart) : sb.xSize;
+    const size_t ny = sb.ySize == SliceBuilder::npos ? outY - std::min(outY, sb.yStart) : sb.ySize;
+    if (sb.xStart + nx > outX || sb.yStart + ny > outY) throw CDMException("slice of " + varName + " exceeds the output grid");
+    if (nx == outX && ny == outY) return full;
+    // slice the x and y direction of the data (:222-232)
+    const size_t levels = full.size / (outX * outY), elem = sizeOfDataType(full.dataType);
+    TypedData out;
+    out.dataType = full.dataType;
+    out.size = levels * ny * nx;
+    out.bytes = shared_array<unsigned char>(new unsigned char[out.size ? out.size * elem : 1]);
+    for (size_t z = 0; z < levels; ++z)
+        for (size_t y = 0; y < ny; ++y) {
+            const unsigned char* src = full.bytes.get() + ((z * outY + sb.yStart + y) * outX + sb.xStart) * elem;
+            std::copy(src, src + nx * elem, out.bytes.get() + (z * ny + y) * nx * elem);
+        }
+    return out;
+}
+
+TypedData CDMInterpolator::regridLevels(const std::string& varName, size_t unLimDimPos, size_t levelStart, size_t levelSize)
+{
     if (!dataReader_->hasVariable(varName)) throw CDMException("variable not found: " + varName);
     if (!cachedInterpolation_) throw CDMException("no cached interpolation for " + varName);  // :247-249
     const VariableInfo var = dataReader_->variable(varName);
-    TypedData data = readTypedInput(varName, unLimDimPos);
+    TypedData data = readTypedInput(varName, unLimDimPos, levelStart, levelSize);
     if (data.size == 0) return data;  // :252-253
     const double badValue = var.hasFillValue ? var.fillValue : defaultFillValue(var.dataType);  // CDM::getFillValue, :254
 
@@ -467,7 +508,7 @@ TypedData CDMInterpolator::getTypedDataSlice(const std::string& varName, size_t 
     bool isX = true, haveCounterpart = false;
     if (rotate) {
         if (cachedVectorReprojection_) {
-            counterpart = readTypedInput(var.counterpart, unLimDimPos);  // :269
+            counterpart = readTypedInput(var.counterpart, unLimDimPos, levelStart, levelSize);  // :269
             haveCounterpart = true;
             const VariableInfo cv = dataReader_->variable(var.counterpart);
             badCounterpart = cv.hasFillValue ? cv.fillValue : defaultFillValue(cv.dataType);

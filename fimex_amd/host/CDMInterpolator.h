@@ -56,6 +56,13 @@ public:
     virtual bool lonLat(std::vector<double>& lon, std::vector<double>& lat) const { (void)lon; (void)lat; return false; }
 };
 
+// What the path needs of include/fimex/SliceBuilder.h: start and size along x, y (of the OUTPUT grid), the level
+// dimension and the unlimited dimension; a size of npos means "to the end"
+struct SliceBuilder {
+    static constexpr size_t npos = static_cast<size_t>(-1);
+    size_t xStart = 0, xSize = npos, yStart = 0, ySize = npos, levelStart = 0, levelSize = npos, unLimDimPos = 0;
+};
+
 // include/fimex/CrossSectionDefinition.h: a named polyline of (longitude, latitude) waypoints in degrees
 struct CrossSectionDefinition {
     std::string name;
@@ -95,6 +102,9 @@ public:
     // the same on the variable's stored type, as the reference's DataPtr-returning getDataSlice: data2InterpolationArray
     // (:115-119) and interpolationArray2Data (:121-124) included, only typed elements cross PCIe
     TypedData getTypedDataSlice(const std::string& varName, size_t unLimDimPos);
+    // getDataSlice(varName, SliceBuilder) (src/CDMInterpolator.cc:162-233): the non-horizontal dimensions are sliced when
+    // the input is read, whole horizontal slices are regridded, the result is cut to the requested x / y range
+    TypedData getTypedDataSlice(const std::string& varName, const SliceBuilder& sb);
 
     // include/fimex/CDMInterpolator.h:246-252: radius (m) of the coord_kdtree search; <= 0: derived from the output axes
     void setDistanceOfInterest(double dist) { maxDistance_ = dist; }
@@ -131,7 +141,8 @@ private:
     void changeProjectionByForwardInterpolation(int method, const std::string& proj_input, std::vector<double> outXAxis,
                                                 std::vector<double> outYAxis, bool xDegree, bool yDegree);
     shared_array<float> readInput(const std::string& varName, size_t unLimDimPos, size_t& size) const;
-    TypedData readTypedInput(const std::string& varName, size_t unLimDimPos) const;
+    TypedData readTypedInput(const std::string& varName, size_t unLimDimPos, size_t levelStart, size_t levelSize) const;
+    TypedData regridLevels(const std::string& varName, size_t unLimDimPos, size_t levelStart, size_t levelSize);
     void processArray(const std::vector<std::shared_ptr<InterpolatorProcess2d>>& processes, float* array, size_t size, size_t nx, size_t ny) const;
 };
 

@@ -15,6 +15,8 @@
 //       vcross_bnds.i32, target_lon.f64, target_lat.f64 and prints "vcross <names...>")
 //   template <file of lon floats> <file of lat floats> <nx> <ny>  (changeProjectionToTemplate)
 //   pre|post fill2d <relaxCrit> <corrEff> <maxLoop> | creepfill2d <repeat> <weight> | creepfillval2d <repeat> <weight> <default>
+//   slice <var> <step> <levelStart> <levelSize> <xStart> <xSize> <yStart> <ySize>   (getDataSlice with a SliceBuilder; output
+//       <out_dir>/<var>_<step>_slice.f32 | .raw)
 //   get <var> <step>              (repeatable; output: <out_dir>/<var>_<step>.f32 for float variables, .raw in the stored type otherwise)
 // Also writes <out_dir>/points_x.f64, points_y.f64 (plan positions) and matrix.f64 (rotation matrix, if any).
 #include <cmath>
@@ -147,6 +149,7 @@ int main(int argc, char** argv)
         std::vector<CrossSectionDefinition> crossSections;
         double maxDist = -1;
         std::vector<std::pair<std::string, size_t>> gets;
+        std::vector<std::pair<std::string, SliceBuilder>> slices;
         std::vector<std::pair<bool, std::shared_ptr<InterpolatorProcess2d>>> procs;
         while (std::getline(spec, line)) {
             std::istringstream in(line);
@@ -201,6 +204,11 @@ int main(int argc, char** argv)
                 else if (kind == "creepfillval2d") { int r, w; float d; in >> r >> w >> d; p = std::make_shared<InterpolatorCreepFillVal2d>((unsigned short)r, (char)w, d); }
                 else throw CDMException("unknown process " + kind);
                 procs.push_back({key == "pre", p});
+            } else if (key == "slice") {
+                std::string v;
+                SliceBuilder sb;
+                in >> v >> sb.unLimDimPos >> sb.levelStart >> sb.levelSize >> sb.xStart >> sb.xSize >> sb.yStart >> sb.ySize;
+                slices.push_back({v, sb});
             } else if (key == "get") { std::string v; size_t s; in >> v >> s; gets.push_back({v, s}); }
         }
         CDMInterpolator interp(reader);
@@ -231,6 +239,12 @@ int main(int argc, char** argv)
             const bool isFloat = out.dataType == FIMEX_AMD_CDM_FLOAT;
             writeAll(outDir + "/" + g.first + "_" + std::to_string(g.second) + (isFloat ? ".f32" : ".raw"), out.bytes.get(),
                      out.size * sizeOfDataType(out.dataType));
+        }
+        for (auto& sl : slices) {
+            const TypedData out = interp.getTypedDataSlice(sl.first, sl.second);
+            const bool isFloat = out.dataType == FIMEX_AMD_CDM_FLOAT;
+            writeAll(outDir + "/" + sl.first + "_" + std::to_string(sl.second.unLimDimPos) + "_slice" + (isFloat ? ".f32" : ".raw"),
+                     out.bytes.get(), out.size * sizeOfDataType(out.dataType));
         }
         return 0;
     } catch (const std::exception& e) {

@@ -360,3 +360,22 @@ def test_coordtest_cross_sections(tmp_path, coordtest):
     want = oracle.interpolation_array2data(want, oracle.CDM_FLOAT, fill)
     got = np.fromfile(out / "air_temperature_0.f32", dtype=np.float32).reshape(-1, 1, wlon.size)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
+
+
+def test_get_data_slice_with_a_slicebuilder(tmp_path, coordtest):
+    """getDataSlice(varName, SliceBuilder) (src/CDMInterpolator.cc:162-233): a range of levels is read, whole horizontal
+    slices are regridded (and rotated for the wind pair), the result is cut to the requested x / y window."""
+    ct = coordtest
+    nlev = ct["cloud_area_fraction_in_atmosphere_layer"].shape[1]
+    assert nlev >= 3
+    lines, lon, lat = _spec_common(tmp_path, ct, "bilinear", [
+        "get cloud_area_fraction_in_atmosphere_layer 1", "get x_wind_10m 2",
+        "slice cloud_area_fraction_in_atmosphere_layer 1 1 2 17 50 120 33",
+        "slice x_wind_10m 2 0 1 0 200 199 1"])
+    out, _ = _run(tmp_path, lines)
+    full = np.fromfile(out / "cloud_area_fraction_in_atmosphere_layer_1.f32", dtype=np.float32).reshape(nlev, 200, 200)
+    part = np.fromfile(out / "cloud_area_fraction_in_atmosphere_layer_1_slice.f32", dtype=np.float32).reshape(2, 33, 50)
+    assert cases.same(part, full[1:3, 120:153, 17:67])
+    wind = np.fromfile(out / "x_wind_10m_2.f32", dtype=np.float32).reshape(-1, 200, 200)
+    row = np.fromfile(out / "x_wind_10m_2_slice.f32", dtype=np.float32).reshape(1, 1, 200)
+    assert cases.same(row, wind[:1, 199:, :])

@@ -24,9 +24,10 @@ constexpr int kFillBlock = 1024;
 
 struct SliceStats {
     unsigned long long nUndef;
-    double average;
-    double meanAbsDev;
-    int status;  // 1 ok, -1 error
+    double average;     // first guess (mean of the defined cells, or the caller's default value)
+    double meanAbsDev;  // fill2d: relaxCrit * mean absolute deviation = the convergence criterion
+    int status;         // 1 ok, -1 error
+    int skip;           // nothing to fill or nothing defined: the slice is left alone
 };
 
 // sum of the defined values in scan order, double accumulator (interpolation.c:1256-1264, 1502-1513);
@@ -445,6 +446,140 @@ __global__ void __launch_bounds__(kFillBlock) fill2d_kernel(Fill2dArgs a)
     (void)kV2Threads; (void)kRowsPerIt; (void)kChunksPerWord; (void)kRingW; (void)kPitch
 constexpr int kMaxBands = 4096;
 
+// ---- what precedes the sweeps of both systolic kernels, as kernels of their own: the sums stay one workgroup per slice
+// (the reference's order of additions), the first guess and the mask words are spread over the chip -- one workgroup
+// streaming a 36 MB slice is latency bound (4 ms of a 15 ms call before the split).
+struct FillStatsArgs {
+    const float* field;
+    SliceStats* stats;
+    size_t total;
+    int wantDeviation;   // fill2d: second pass for the convergence criterion (:1284-1302)
+    int useDefault;      // creepfillval2d: the caller's value is the first guess, only the undefined cells are counted
+    float defaultVal;
+    float relaxCrit;
+    int sumAlgo;
+};
+
+__global__ void __launch_bounds__(kFillBlock) fill_stats_kernel(FillStatsArgs a)
+{
+    __shared__ __align__(16) double lds[2 * kSumTile];
+    __shared__ double shAverage;
+    __shared__ unsigned long long shUndef;
+    const float* f = a.field + (size_t)blockIdx.x * a.total;
+    SliceStats* st = a.stats + blockIdx.x;
+    unsigned long long nUndef = 0;
+    const double sum = scan_order_sum(f, a.total, a.useDefault ? 2 : 0, 0., lds, &nUndef, a.sumAlgo);
+    if (threadIdx.x == 0) {
+        const unsigned long long nDef = a.total - nUndef;
+        shUndef = nUndef;
+        shAverage = a.useDefault ? (double)a.defaultVal : ((nDef != 0) ? sum / (double)nDef : 0.);  // :1281, :1516
+        st->nUndef = nUndef;
+        st->average = shAverage;
+        st->status = 1;
+        st->skip = (nDef == 0 || nUndef == 0);  // :1266-1269, :1384-1386
+    }
+    __syncthreads();
+    nUndef = shUndef;
+    const unsigned long long nDef = a.total - nUndef;
+    if (!a.wantDeviation || nDef == 0 || nUndef == 0) return;
+    const double dev = scan_order_sum(f, a.total, 1, shAverage, lds, nullptr, a.sumAlgo);
+    if (threadIdx.x == 0) st->meanAbsDev = (double)a.relaxCrit * (dev / (double)nDef);  // :1302
+}
+
+struct FirstGuessArgs {
+    float* field;
+    const SliceStats* stats;
+    uint32_t* mask;           // [nz][ny][mws]: fill2d NaN bits of the interior rows, creepfill "defined" bits of all rows
+    unsigned char* mbRows;    // fill2d: [nz][2][nx] NaN mask of row 0 and row ny - 1
+    unsigned char* mbCols;    // fill2d: [nz][2][ny] NaN mask of column 0 and column nx - 1
+    uint32_t nx, ny, mws;
+};
+
+// One wave per row: undefined cells take the first guess (:1288-1299, :1408-1421) and the mask words are written in the
+// row's skew (interior row y: bit x + ((y - 1) & 63)), eight row pieces in flight per wave.
+template <bool CREEP>
+__global__ void __launch_bounds__(kBlock) first_guess_kernel(FirstGuessArgs a)
+{
+    const SliceStats st = a.stats[blockIdx.y];
+    if (st.skip) return;
+    const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t y = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (y >= ny) return;
+    const float guess = (float)st.average;
+    float* row = a.field + ((size_t)blockIdx.y * ny + y) * nx;
+    const bool edgeRow = y == 0 || y == ny - 1;
+    if (!CREEP && edgeRow) {
+        unsigned char* mb = a.mbRows + ((size_t)blockIdx.y * 2 + (y == 0 ? 0 : 1)) * nx;
+        for (uint32_t x = lane; x < nx; x += kWave) {
+            const bool u = isnan(row[x]);
+            mb[x] = u;
+            if (u) row[x] = guess;
+        }
+        return;
+    }
+    const uint32_t l = edgeRow ? 0u : ((y - 1) & (kWave - 1));
+    uint32_t* mrow = a.mask + ((size_t)blockIdx.y * ny + y) * mws;
+    unsigned char* mbLeft = CREEP ? nullptr : a.mbCols + (size_t)blockIdx.y * 2 * ny;
+    constexpr int kAhead = 8;
+    for (uint32_t base0 = 0; base0 < mws * 32; base0 += kAhead * kWave) {
+        float v[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const int64_t x = (int64_t)base0 + k * kWave + lane - l;
+            v[k] = (x >= 0 && x < (int64_t)nx && base0 + k * kWave < mws * 32) ? row[x] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const uint32_t base = base0 + k * kWave;
+            if (base >= mws * 32) break;
+            const int64_t x = (int64_t)base + lane - l;
+            const bool in = x >= 0 && x < (int64_t)nx;
+            const bool u = in && isnan(v[k]);
+            const unsigned long long m = __ballot(CREEP ? (in && !u) : u);
+            if (lane == 0) {
+                mrow[base / 32] = (uint32_t)m;
+                if (base / 32 + 1 < mws) mrow[base / 32 + 1] = (uint32_t)(m >> 32);
+            }
+            if (u) row[x] = guess;
+            if (!CREEP) {
+                if (in && x == 0) mbLeft[y] = u;
+                if (in && x == (int64_t)nx - 1) mbLeft[ny + y] = u;
+            }
+        }
+    }
+}
+
+void launch_fill_prologue(bool creep, float* d_field, SliceStats* d_stats, size_t nx, size_t ny, size_t nz, uint32_t* mask, uint32_t mws,
+                          unsigned char* mbRows, unsigned char* mbCols, bool wantDeviation, bool useDefault, float defaultVal, float relaxCrit,
+                          hipStream_t stream)
+{
+    FillStatsArgs s{};
+    s.field = d_field;
+    s.stats = d_stats;
+    s.total = nx * ny;
+    s.wantDeviation = wantDeviation;
+    s.useDefault = useDefault;
+    s.defaultVal = defaultVal;
+    s.relaxCrit = relaxCrit;
+    s.sumAlgo = tuning("SUM_ALGO", 1);
+    fill_stats_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(s);
+    FA_HIP(hipGetLastError());
+    FirstGuessArgs g{};
+    g.field = d_field;
+    g.stats = d_stats;
+    g.mask = mask;
+    g.mbRows = mbRows;
+    g.mbCols = mbCols;
+    g.nx = (uint32_t)nx;
+    g.ny = (uint32_t)ny;
+    g.mws = mws;
+    const dim3 grid((uint32_t)ceil_div(ny, (size_t)(kBlock / kWave)), (uint32_t)nz);
+    if (creep) first_guess_kernel<true><<<grid, kBlock, 0, stream>>>(g);
+    else first_guess_kernel<false><<<grid, kBlock, 0, stream>>>(g);
+    FA_HIP(hipGetLastError());
+}
+
 struct Fill2dV2Args {
     float* field;
     uint32_t* maskS;          // [nz][ny][mws] skewed NaN-mask words of the interior rows
@@ -795,8 +930,6 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
 {
     FILL_GEOMETRY(CH, WAVES);
     extern __shared__ __attribute__((aligned(16))) float smem[];  // rings [16][64][33] floats, hand-off [16][2][192] + counters
-    __shared__ double shAverage, shCrit;
-    __shared__ unsigned long long shUndef;
     float* rings = smem;
     Handoff hand;
     hand.data = smem + kV2Waves * kWave * kPitch;
@@ -811,57 +944,11 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
     unsigned char* mbLeft = a.mbCols + (size_t)blockIdx.x * 2 * ny;
     unsigned char* mbRight = mbLeft + ny;
     SliceStats* st = a.stats + blockIdx.x;
-    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t wave = threadIdx.x / kWave;
 
-    unsigned long long nUndef = 0;
-    const double sum = scan_order_sum<kV2Threads>(f, total, 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumAlgo);
-    if (threadIdx.x == 0) {
-        shUndef = nUndef;
-        const unsigned long long nDef = total - nUndef;
-        shAverage = (nDef != 0) ? sum / (double)nDef : 0.;
-        st->nUndef = nUndef;
-        st->status = 1;
-    }
-    __syncthreads();
-    nUndef = shUndef;
-    const unsigned long long nDef = total - nUndef;
-    if (nDef == 0 || nUndef == 0) return;
-    const double average = shAverage;
-    const double dev = scan_order_sum<kV2Threads>(f, total, 1, average, reinterpret_cast<double*>(smem), nullptr, a.sumAlgo);
-    if (threadIdx.x == 0) shCrit = (double)a.relaxCrit * (dev / (double)nDef);
-    __syncthreads();
-    const double crit = shCrit;
-    const float avgf = (float)average;
-
-    // first guess + masks (:1288-1299).  Interior rows: one wave per row, skewed ballot words.
-    for (uint32_t y = wave; y < ny; y += kV2Waves) {
-        float* row = f + (size_t)y * nx;
-        if (y == 0 || y == ny - 1) {
-            unsigned char* mb = (y == 0) ? mbTop : mbBot;
-            for (uint32_t x = lane; x < nx; x += kWave) {
-                const bool u = isnan(row[x]);
-                mb[x] = u;
-                if (u) row[x] = avgf;
-            }
-        } else {
-            const uint32_t l = (y - 1) & (kWave - 1);
-            uint32_t* mrow = maskS + (size_t)y * mws;
-            for (uint32_t base = 0; base < mws * 32; base += kWave) {
-                const int64_t x = (int64_t)base + lane - l;
-                const bool in = x >= 0 && x < (int64_t)nx;
-                const bool u = in && isnan(row[in ? x : 0]);
-                const unsigned long long m = __ballot(u);
-                if (lane == 0) {
-                    mrow[base / 32] = (uint32_t)m;
-                    if (base / 32 + 1 < mws) mrow[base / 32 + 1] = (uint32_t)(m >> 32);
-                }
-                if (u) row[x] = avgf;
-                if (in && x == 0) mbLeft[y] = u;
-                if (in && x == (int64_t)nx - 1) mbRight[y] = u;
-            }
-        }
-    }
-    __syncthreads();
+    // sums, first guess and masks were made by fill_stats_kernel / first_guess_kernel
+    if (st->skip) return;  // :1266-1269
+    const double crit = st->meanAbsDev;
 
     const float wInt = 1.f * a.corrEff, wZero = 0.f * a.corrEff;  // :1311-1315
     const float crtest = (float)(crit * a.corrEff);
@@ -1391,8 +1478,6 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
 __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ unsigned long long shUndef;
-    __shared__ float shDefault;
     float* rings = smem;
     HandoffC hand;
     hand.data = smem + kCreepWaves * kWave * kCreepPitch;
@@ -1406,44 +1491,13 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
     uint32_t* maskD = a.maskD + (size_t)blockIdx.x * maskWords;
     uint32_t* maskU = a.maskU + (size_t)blockIdx.x * a.gens * maskWords;
     SliceStats* st = a.stats + blockIdx.x;
-    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t wave = threadIdx.x / kWave;
 
-    unsigned long long nUndef = 0;
-    const double sum = scan_order_sum<kCreepThreads>(f, total, a.useDefault ? 2 : 0, 0., reinterpret_cast<double*>(smem), &nUndef, a.sumAlgo);
-    if (threadIdx.x == 0) {
-        shUndef = nUndef;
-        const unsigned long long nDef = total - nUndef;
-        shDefault = a.useDefault ? a.defaultVal : ((nDef != 0) ? (float)(sum / (double)nDef) : 0.f);  // :1516
-        st->nUndef = nUndef;
-        st->status = 1;
-    }
-    __syncthreads();
-    nUndef = shUndef;
-    const unsigned long long nDef = total - nUndef;
-    if (nDef == 0 || nUndef == 0) return;  // :1384-1386, :1515
-    const float defaultVal = shDefault;
+    // sum, first guess and the D mask were made by fill_stats_kernel / first_guess_kernel
+    if (st->skip) return;  // :1384-1386, :1515
+    const unsigned long long nDef = total - st->nUndef;
     const uint32_t repeat = a.repeat;
     const float swf = (float)a.setWeight;
-
-    // first guess and the D mask (:1408-1421): one wave per row, ballot words in the row's skew
-    for (uint32_t y = wave; y < ny; y += kCreepWaves) {
-        float* row = f + (size_t)y * nx;
-        const uint32_t l = (y == 0 || y == ny - 1) ? 0u : ((y - 1) & (kWave - 1));
-        uint32_t* mrow = maskD + (size_t)y * mws;
-        for (uint32_t base = 0; base < mws * 32; base += kWave) {
-            const int64_t x = (int64_t)base + lane - l;
-            const bool in = x >= 0 && x < (int64_t)nx;
-            const float val = in ? row[x] : 0.f;
-            const bool undef = in && isnan(val);
-            const unsigned long long m = __ballot(in && !undef);
-            if (lane == 0) {
-                mrow[base / 32] = (uint32_t)m;
-                if (base / 32 + 1 < mws) mrow[base / 32 + 1] = (uint32_t)(m >> 32);
-            }
-            if (undef) row[x] = defaultVal;
-        }
-    }
-    __syncthreads();
 
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
     const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
@@ -1548,6 +1602,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         a.corrEff = corrEff;
         a.maxLoop = maxLoop;
         a.sumAlgo = tuning("SUM_ALGO", 1);
+        launch_fill_prologue(false, d_field, stats.get(), nx, ny, nz, maskS.get(), mws, mbRows.get(), mbCols.get(), true, false, 0.f, relaxCrit, stream);
         // small batches and short calls: 16 waves x 16 columns; from FILL_WIDE_NZ slices on: 8 waves x 32 columns
         const int geometry = tuning("FILL_GEOMETRY", 0);  // 0: by batch size, 1: 16 x 16, 2: 8 x 32
         const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 48));
@@ -1613,6 +1668,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         a.skipIdle = tuning("CREEP_SKIP", 1);
         constexpr size_t ldsBytes = (size_t)kCreepWaves * kWave * kCreepPitch * sizeof(float) + (size_t)kCreepWaves * 2 * kHandWC * (sizeof(float) + 1) +
                                     (size_t)kCreepWaves * 4 * sizeof(unsigned int);
+        launch_fill_prologue(true, d_field, stats.get(), nx, ny, nz, maskD.get(), mws, nullptr, nullptr, false, useDefault, defaultVal, 0.f, stream);
         allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
         creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);
         FA_HIP(hipGetLastError());

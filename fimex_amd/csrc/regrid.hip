@@ -641,6 +641,11 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
 bool launch_typed_apply(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
                         hipStream_t stream)
 {
+    // 1- and 2-byte types through the LDS-staged kernels (the same dispatch rule as for floats)
+    if (plan.kind != PlanKind::Forward && tuning("TYPED_FUSED", 1) != 0 && plan.staged.valid && tuning("STAGED", 1) != 0 && tuning("TYPED_STAGED", 1) != 0 &&
+        nz >= (size_t)tuning("STAGED_MIN_NZ", 4) && (plan.kind != PlanKind::Nearest || tuning("STAGED_NEAREST", 1) != 0) &&
+        launch_staged_apply_typed(plan, d_in, cdmType, nz, badValue, d_out, stream))
+        return true;
     // bicubic: the LDS-staged float kernel between two conversion passes beats a 16-load gather on the stored type
     if (plan.kind == PlanKind::Forward || (plan.kind == PlanKind::Bicubic && tuning("TYPED_FUSED", 1) < 2) || tuning("TYPED_FUSED", 1) == 0) return false;
     if (!(cdmType == FIMEX_AMD_CDM_CHAR || cdmType == FIMEX_AMD_CDM_UCHAR || cdmType == FIMEX_AMD_CDM_SHORT ||

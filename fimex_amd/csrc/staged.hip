@@ -18,6 +18,9 @@
 // 2-4 slices of prefetch depth (equal), non-temporal loads (-15 %), plain stores (-6 %), XCD-contiguous or striped
 // tile orders (equal or worse than plain round-robin).
 #include "plan.hpp"
+#include "typed_convert.hpp"
+
+#include <type_traits>
 
 namespace fimex_amd {
 
@@ -192,8 +195,11 @@ __global__ void __launch_bounds__(kBlock) build_tiles(const double* __restrict__
 }
 
 struct StagedArgs {
-    const float* in;
-    float* out;
+    const void* in;     // elements of T: float, or the variable's stored type
+    void* out;
+    float bad;          // stored types: the fill value narrowed to float (mifi_bad2nanf's parameter), whether there is one,
+    int hasBad;         // and the fill value as interpolationArray2Data receives it
+    double fillOut;
     const uint32_t* tileRows;
     const uint2* tileHdr;
     const uint32_t* ldsA;
@@ -211,9 +217,9 @@ struct StagedArgs {
 };
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const float* base, uint32_t bytes)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
 // One LDS-DMA wave instruction: 64 lanes x 16 bytes from per-lane buffer offsets to ldsBase + lane * 16.
@@ -232,6 +238,38 @@ __device__ __forceinline__ void dma16(rsrc_t rs, float* ldsBase, uint32_t voff, 
 #else
     (void)rs; (void)ldsBase; (void)voff; (void)aux;
 #endif
+}
+
+// The same with 4 bytes per lane (256 bytes per wave instruction): sources of 1- and 2-byte elements, whose row segments
+// start on 4-byte but not on 16-byte boundaries.
+__device__ __forceinline__ void dma4(rsrc_t rs, void* ldsBase, uint32_t voff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 4, voff, 0, 0, 0);
+#else
+    (void)rs; (void)ldsBase; (void)voff;
+#endif
+}
+
+// one element of the staged image as float (stored types: Data::asFloat + mifi_bad2nanf, typed_convert.hpp)
+template <typename T>
+__device__ __forceinline__ float lds_value(const char* buf, uint32_t floatByteOff, float bad, bool hasBad)
+{
+    if constexpr (std::is_same<T, float>::value) return *reinterpret_cast<const float*>(buf + floatByteOff);
+    else return as_float_nan(*reinterpret_cast<const T*>(buf + floatByteOff / 4 * sizeof(T)), bad, hasBad);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_result(rsrc_t ro, uint32_t cellByteOff, float r, T fill)
+{
+    if constexpr (std::is_same<T, float>::value) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellByteOff, 0, 2);
+    else {
+        const T v = from_float_fill<T>(r, fill);  // interpolationArray2Data: NaN -> fill value, integers rounded
+        if constexpr (sizeof(T) == 1) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, ro, cellByteOff / 4, 0, 2);
+        else if constexpr (sizeof(T) == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, ro, cellByteOff / 2, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, ro, cellByteOff, 0, 2);
+    }
 }
 
 // Keys kernel a = -0.5: rows of M/2 (src/interpolation.c:962-968), weights XM / MY (:977-1000)
@@ -265,9 +303,19 @@ __device__ __forceinline__ void wait_vmcnt()
 
 // NBUF: LDS buffers of the slice ring; NBUF - 1 slices are in flight while one is interpolated.  What a workgroup waits
 // for per slice is the latency of its DMA, so the bytes in flight per CU (LDS capacity x (NBUF - 1) / NBUF) set the rate.
-template <int STENCIL, int PER, int KMAX, int NBUF>
+// T: float, or the variable's stored type -- the same tiles and LDS offsets (in elements), the staged image holds
+// elements of T (1- and 2-byte types arrive through 4-byte DMA pieces), values become float on the LDS read and go back to
+// T on the store.
+template <int STENCIL, int PER, int KMAX, int NBUF, typename T = float>
 __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
 {
+    constexpr bool kFloat = std::is_same<T, float>::value;
+    constexpr uint32_t EB = sizeof(T);
+    // DMA pieces per lane and slice: 16-byte chunks for 4-byte elements, 4-byte pieces otherwise (a chunk of the plan is
+    // 4 elements = 4 * EB bytes = EB pieces)
+    constexpr int UN = (EB == 4) ? KMAX : KMAX * (int)EB;
+    const bool hasBad = a.hasBad != 0;
+    const T fillT = kFloat ? T() : static_cast<T>(a.fillOut);  // ScaleValue's newFill_ (Utils.h:456)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // NBUF buffers of KMAX*256*4 floats (+ slack), then the row table
     constexpr uint32_t kBufFloats = KMAX * kBlock * 4 + 4;
     uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + NBUF * kBufFloats);  // [2 * nr]
@@ -325,13 +373,15 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
             cubic_weights(fy, MY[k]);
         }
     }
-    const uint32_t outBytes = a.nOut * 4u;
+    const uint32_t outBytes = a.nOut * EB;
+    const char* inBase = static_cast<const char*>(a.in);
+    char* outBase = static_cast<char*>(a.out);
 
     if (totalChunks == 0) {  // nothing of the source is needed: every output of the tile is undefined
         for (uint32_t z = z0; z < z1; ++z) {
-            const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, outBytes);
+            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outBytes);
 #pragma unroll
-            for (int k = 0; k < PER; ++k) __builtin_amdgcn_raw_buffer_store_b32(0x7fc00000u, ro, cellOff[k], 0, 2);
+            for (int k = 0; k < PER; ++k) store_result<T>(ro, cellOff[k], undefined_f(), fillT);
         }
         return;
     }
@@ -340,10 +390,12 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     const uint32_t* rows = a.tileRows + (size_t)tile * 2 * kMaxRows;
     for (uint32_t i = threadIdx.x; i < 2 * nr; i += kBlock) shRows[i] = rows[i];
     __syncthreads();
-    uint32_t gOff[KMAX];  // byte offset of the chunk inside a source slice, ~0u = none (dropped by the bounds check: zeros)
+    // piece u = threadIdx.x + j*256: 16-byte chunk u (4-byte elements), or 4-byte piece u % EB of chunk u / EB
+    uint32_t gOff[UN];  // byte offset of the piece inside a source slice, ~0u = none (dropped by the bounds check: zeros)
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-        const uint32_t c = threadIdx.x + j * kBlock;
+    for (int j = 0; j < UN; ++j) {
+        const uint32_t u = threadIdx.x + j * kBlock;
+        const uint32_t c = (EB == 4) ? u : u / EB;
         gOff[j] = 0xFFFFFFFFu;
         if (c < totalChunks) {
             uint32_t lo = 0, hi = nr - 1;  // last row whose first chunk <= c
@@ -351,17 +403,21 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                 const uint32_t mid = (lo + hi + 1) >> 1;
                 if (shRows[2 * mid + 1] <= c) lo = mid; else hi = mid - 1;
             }
-            gOff[j] = (shRows[2 * lo] + (c - shRows[2 * lo + 1]) * 4u) * 4u;
+            const uint32_t elem = shRows[2 * lo] + (c - shRows[2 * lo + 1]) * 4u;  // first element of the chunk
+            gOff[j] = (EB == 4) ? elem * 4u : elem * EB + (u % EB) * 4u;
         }
     }
 
-    const uint32_t inBytes = (uint32_t)a.inLayer * 4u;
-    // one wave instruction moves 64 chunks = 1 KiB: LDS destination = wave-uniform base + lane * 16
+    const uint32_t inBytes = (uint32_t)a.inLayer * EB;
+    // one wave instruction moves 64 pieces (1 KiB or 256 bytes): LDS destination = wave-uniform base + lane * piece size
     const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
     auto dma = [&](float* dst, uint32_t z) {
-        const rsrc_t rs = make_rsrc(a.in + (size_t)z * a.inLayer, (a.ablate & 1) ? 0u : inBytes);
+        const rsrc_t rs = make_rsrc(inBase + (size_t)z * inBytes, (a.ablate & 1) ? 0u : inBytes);
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
+        for (int j = 0; j < UN; ++j) {
+            if constexpr (EB == 4) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
+            else dma4(rs, dst + (waveChunk + j * kBlock), gOff[j]);
+        }
     };
 
     // prologue: NBUF - 1 slices in flight, the first one landed (NBUF == 1: no prefetch, the slice is fetched, then used)
@@ -383,22 +439,29 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
             dma(smem + ((slot + NBUF - 1) % NBUF) * kBufFloats, z + (NBUF - 1));  // into the buffer slice z - 1 has left
         }
         const float* cur = smem + slot * kBufFloats;
-        const rsrc_t ro = make_rsrc(a.out + (size_t)z * a.nOut, (a.ablate & 2) ? 0u : outBytes);
+        const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, (a.ablate & 2) ? 0u : outBytes);
         const char* curb = reinterpret_cast<const char*>(cur);
         if constexpr (STENCIL == 1) {
             float v[PER];
 #pragma unroll
-            for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
+            for (int k = 0; k < PER; ++k) v[k] = lds_value<T>(curb, row[k][0], a.bad, hasBad);
 #pragma unroll
-            for (int k = 0; k < PER; ++k)
-                __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);  // :869-876
+            for (int k = 0; k < PER; ++k) {
+                if constexpr (kFloat) __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);  // :869-876
+                else store_result<T>(ro, cellOff[k], undef[k] ? undefined_f() : v[k], fillT);
+            }
         } else if constexpr (STENCIL == 2) {
             float s00[PER], s01[PER], s10[PER], s11[PER];
 #pragma unroll
             for (int k = 0; k < PER; ++k) {  // all stencil reads first: 2 x ds_read2_b32 per output, no waits in between
-                const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
-                const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
-                s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
+                if constexpr (kFloat) {
+                    const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
+                    const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
+                    s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
+                } else {
+                    s00[k] = lds_value<T>(curb, row[k][0], a.bad, hasBad); s01[k] = lds_value<T>(curb, row[k][0] + 4, a.bad, hasBad);
+                    s10[k] = lds_value<T>(curb, row[k][1], a.bad, hasBad); s11[k] = lds_value<T>(curb, row[k][1] + 4, a.bad, hasBad);
+                }
             }
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -410,6 +473,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                 const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
                 float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
                 r = undef[k] ? undefined_f() : r;
+                if constexpr (!kFloat) { store_result<T>(ro, cellOff[k], r, fillT); continue; }
                 switch (a.storeAux) {  // cache policy of the result stores (wave-uniform): 2 = non-temporal is the default
                 case 0: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 0); break;
                 case 1: __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 1); break;
@@ -427,9 +491,8 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                 float f[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float* pr = reinterpret_cast<const float*>(curb + row[k][i]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f[i][j] = pr[j];
+                    for (int j = 0; j < 4; ++j) f[i][j] = lds_value<T>(curb, row[k][i] + 4 * j, a.bad, hasBad);
                 }
                 float acc = 0;  // interpolation.c:1005: accumulates into the float output
 #pragma unroll
@@ -440,14 +503,14 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                     acc = (float)((double)acc + xmf * MY[k][i]);                    // :1019
                 }
                 const float r = undef[k] ? undefined_f() : acc;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+                store_result<T>(ro, cellOff[k], r, fillT);
             }
         }
         // Slice z + 1 must have landed.  Results come back in issue order: behind its DMA are the DMAs of slices
         // z + 2 .. z + NBUF - 1 and the stores of NBUF - 1 slices, which may all stay in flight.  At the end of the run
         // (no new DMA issued) only this slice's stores may.
         if (NBUF == 1) { /* the buffer is rewritten after the barrier below */ }
-        else if (more) wait_vmcnt<(NBUF >= 2 ? (NBUF - 2) * KMAX + (NBUF - 1) * PER : 0)>();
+        else if (more) wait_vmcnt<(NBUF >= 2 ? (NBUF - 2) * UN + (NBUF - 1) * PER : 0)>();
         else wait_vmcnt<PER>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -455,31 +518,33 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     }
 }
 
-template <int STENCIL, int PER, int KMAX, int NBUF>
+template <int STENCIL, int PER, int KMAX, int NBUF, typename T>
 void launch_staged_n(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
     constexpr size_t ldsBytes = (size_t)NBUF * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
     static_assert(ldsBytes <= 160 * 1024, "slice ring does not fit the CU's LDS");
-    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX, NBUF>), ldsBytes);
-    staged_apply<STENCIL, PER, KMAX, NBUF><<<grid, kBlock, ldsBytes, stream>>>(a);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX, NBUF, T>), ldsBytes);
+    staged_apply<STENCIL, PER, KMAX, NBUF, T><<<grid, kBlock, ldsBytes, stream>>>(a);
 }
 
-template <int STENCIL, int PER, int KMAX>
+template <int STENCIL, int PER, int KMAX, typename T>
 void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
-    constexpr size_t buf = (size_t)(KMAX * kBlock * 4 + 4) * sizeof(float);
-    const int nbuf = tuning("STAGE_NBUF", 2);
-    if (nbuf == 1) { launch_staged_n<STENCIL, PER, KMAX, 1>(a, grid, stream); return; }
-    if constexpr (3 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
-        if (nbuf == 3) { launch_staged_n<STENCIL, PER, KMAX, 3>(a, grid, stream); return; }
+    if constexpr (std::is_same<T, float>::value) {  // ring depths other than 2 are experiment switches of the float kernel
+        constexpr size_t buf = (size_t)(KMAX * kBlock * 4 + 4) * sizeof(float);
+        const int nbuf = tuning("STAGE_NBUF", 2);
+        if (nbuf == 1) { launch_staged_n<STENCIL, PER, KMAX, 1, T>(a, grid, stream); return; }
+        if constexpr (3 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
+            if (nbuf == 3) { launch_staged_n<STENCIL, PER, KMAX, 3, T>(a, grid, stream); return; }
+        }
+        if constexpr (4 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
+            if (nbuf == 4) { launch_staged_n<STENCIL, PER, KMAX, 4, T>(a, grid, stream); return; }
+        }
+        if constexpr (6 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024 && (4 * KMAX + 5 * PER) < 64) {
+            if (nbuf == 6) { launch_staged_n<STENCIL, PER, KMAX, 6, T>(a, grid, stream); return; }
+        }
     }
-    if constexpr (4 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
-        if (nbuf == 4) { launch_staged_n<STENCIL, PER, KMAX, 4>(a, grid, stream); return; }
-    }
-    if constexpr (6 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024 && (4 * KMAX + 5 * PER) < 64) {
-        if (nbuf == 6) { launch_staged_n<STENCIL, PER, KMAX, 6>(a, grid, stream); return; }
-    }
-    launch_staged_n<STENCIL, PER, KMAX, 2>(a, grid, stream);
+    launch_staged_n<STENCIL, PER, KMAX, 2, T>(a, grid, stream);
 }
 
 template <int STENCIL>
@@ -560,12 +625,12 @@ bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const do
     return false;
 }
 
-void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+namespace {
+
+template <typename T>
+void launch_staged_t(const fimex_amd_regrid_plan& plan, StagedArgs& a, size_t nz, hipStream_t stream)
 {
     const auto& s = plan.staged;
-    StagedArgs a{};
-    a.in = d_in;
-    a.out = d_out;
     a.tileRows = s.tileRows.get();
     a.tileHdr = s.tileHdr.get();
     a.ldsA = s.ldsA.get();
@@ -604,29 +669,64 @@ void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, s
     const uint32_t key = s.per * 100 + s.kmax;
     if (plan.kind == PlanKind::Nearest) {
         switch (key) {
-        case 404: launch_staged<1, 4, 4>(a, grid, stream); break;
-        case 406: launch_staged<1, 4, 6>(a, grid, stream); break;
-        case 808: launch_staged<1, 8, 8>(a, grid, stream); break;
+        case 404: launch_staged<1, 4, 4, T>(a, grid, stream); break;
+        case 406: launch_staged<1, 4, 6, T>(a, grid, stream); break;
+        case 808: launch_staged<1, 8, 8, T>(a, grid, stream); break;
         default: throw Error("staged nearest: unexpected tile shape");
         }
     } else if (plan.kind == PlanKind::Bilinear) {
         switch (key) {
-        case 404: launch_staged<2, 4, 4>(a, grid, stream); break;
-        case 406: launch_staged<2, 4, 6>(a, grid, stream); break;
-        case 808: launch_staged<2, 8, 8>(a, grid, stream); break;
-        case 812: launch_staged<2, 8, 12>(a, grid, stream); break;
+        case 404: launch_staged<2, 4, 4, T>(a, grid, stream); break;
+        case 406: launch_staged<2, 4, 6, T>(a, grid, stream); break;
+        case 808: launch_staged<2, 8, 8, T>(a, grid, stream); break;
+        case 812: launch_staged<2, 8, 12, T>(a, grid, stream); break;
         default: throw Error("staged bilinear: unexpected tile shape");
         }
     } else {
         switch (key) {
-        case 203: launch_staged<4, 2, 3>(a, grid, stream); break;
-        case 204: launch_staged<4, 2, 4>(a, grid, stream); break;
-        case 406: launch_staged<4, 4, 6>(a, grid, stream); break;
-        case 408: launch_staged<4, 4, 8>(a, grid, stream); break;
+        case 203: launch_staged<4, 2, 3, T>(a, grid, stream); break;
+        case 204: launch_staged<4, 2, 4, T>(a, grid, stream); break;
+        case 406: launch_staged<4, 4, 6, T>(a, grid, stream); break;
+        case 408: launch_staged<4, 4, 8, T>(a, grid, stream); break;
         default: throw Error("staged bicubic: unexpected tile shape");
         }
     }
     FA_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    StagedArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    launch_staged_t<float>(plan, a, nz, stream);
+}
+
+// The staged kernels on a variable's stored type (1- and 2-byte integers): what typed_apply (regrid.hip) does with
+// gathers, through the LDS image.  false: not applicable (type, alignment), the caller takes another path.
+bool launch_staged_apply_typed(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                               hipStream_t stream)
+{
+    if (!plan.staged.valid) return false;
+    if (!(cdmType == FIMEX_AMD_CDM_CHAR || cdmType == FIMEX_AMD_CDM_UCHAR || cdmType == FIMEX_AMD_CDM_SHORT || cdmType == FIMEX_AMD_CDM_USHORT))
+        return false;
+    // 4-byte DMA pieces: slices and row segments start on 4-byte boundaries (inX % 4 == 0 holds for every staged plan)
+    if (reinterpret_cast<uintptr_t>(d_in) % 4 != 0) return false;
+    StagedArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.bad = (float)badValue;
+    a.hasBad = !(a.bad != a.bad);
+    a.fillOut = badValue;
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: launch_staged_t<signed char>(plan, a, nz, stream); break;
+    case FIMEX_AMD_CDM_UCHAR: launch_staged_t<unsigned char>(plan, a, nz, stream); break;
+    case FIMEX_AMD_CDM_SHORT: launch_staged_t<short>(plan, a, nz, stream); break;
+    default: launch_staged_t<unsigned short>(plan, a, nz, stream); break;
+    }
+    return true;
 }
 
 }  // namespace fimex_amd

@@ -673,10 +673,13 @@ def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, 
     plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
     t = torch.from_numpy(f.view(np.uint8)).cuda()
     results = []
-    for fused in ("2", "1", "0"):  # 2: also bicubic through the stored-type kernel
+    # TYPED_STAGED 1: 1- and 2-byte types through the LDS-staged kernels; 0: the gather kernels on the stored type
+    # TYPED_FUSED 2: also bicubic through the stored-type gather kernel; 0: three passes
+    for staged, fused in (("1", "1"), ("0", "2"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("FIMEX_AMD_TYPED_STAGED", staged)
         monkeypatch.setenv("FIMEX_AMD_TYPED_FUSED", fused)
         out = torch.zeros(nz * outY * outX * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
         fa.regrid_apply_typed_device(plan, t.data_ptr(), code, nz, bad, out.data_ptr())
         torch.cuda.synchronize()
         results.append(out.cpu().numpy().view(dt).reshape(want.shape))
-        assert np.array_equal(results[-1].view(np.uint8), want.view(np.uint8)), (fused, np.dtype(dt).name)
+        assert np.array_equal(results[-1].view(np.uint8), want.view(np.uint8)), (staged, fused, np.dtype(dt).name)

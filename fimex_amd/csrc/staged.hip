@@ -530,19 +530,22 @@ void launch_staged_n(const StagedArgs& a, dim3 grid, hipStream_t stream)
 template <int STENCIL, int PER, int KMAX, typename T>
 void launch_staged(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
-    if constexpr (std::is_same<T, float>::value) {  // ring depths other than 2 are experiment switches of the float kernel
-        constexpr size_t buf = (size_t)(KMAX * kBlock * 4 + 4) * sizeof(float);
-        const int nbuf = tuning("STAGE_NBUF", 2);
+    constexpr bool kFloat = std::is_same<T, float>::value;
+    constexpr size_t buf = (size_t)(KMAX * kBlock * 4 + 4) * sizeof(float);
+    constexpr int UN = sizeof(T) == 4 ? KMAX : KMAX * (int)sizeof(T);
+    // a ring of 3 was measured for the stored types as well (256-byte DMA instructions): slower than 2 (2.11 against 1.87 ms)
+    const int nbuf = kFloat ? tuning("STAGE_NBUF", 2) : tuning("TYPED_NBUF", 2);
+    if constexpr (kFloat) {  // 1, 4 and 6 are experiment switches of the float kernel
         if (nbuf == 1) { launch_staged_n<STENCIL, PER, KMAX, 1, T>(a, grid, stream); return; }
-        if constexpr (3 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
-            if (nbuf == 3) { launch_staged_n<STENCIL, PER, KMAX, 3, T>(a, grid, stream); return; }
-        }
         if constexpr (4 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024) {
             if (nbuf == 4) { launch_staged_n<STENCIL, PER, KMAX, 4, T>(a, grid, stream); return; }
         }
         if constexpr (6 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024 && (4 * KMAX + 5 * PER) < 64) {
             if (nbuf == 6) { launch_staged_n<STENCIL, PER, KMAX, 6, T>(a, grid, stream); return; }
         }
+    }
+    if constexpr (3 * buf + 2 * kMaxRows * sizeof(uint32_t) <= 160 * 1024 && (UN + 2 * PER) < 64) {
+        if (nbuf == 3) { launch_staged_n<STENCIL, PER, KMAX, 3, T>(a, grid, stream); return; }
     }
     launch_staged_n<STENCIL, PER, KMAX, 2, T>(a, grid, stream);
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fixed (per call, sweep-independent) cost of fill2d: the two scan-order sums.  Knob: FIMEX_AMD_SUM_ALGO (0 chain, 1 binade-parallel)."""
+"""Fixed (per call, sweep-independent) cost of fill2d: the two scan-order sums.  Knob: FIMEX_AMD_SUM_ALGO (0 chain, 1 binade-parallel in one workgroup, 2 over the whole chip)."""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ st = torch.cuda.current_stream().cuda_stream
 nx, ny = 3000, 3000
 h = cases.holes(1, ny, nx, seed=4, frac=0.3)[0]
 d0 = torch.from_numpy(h[None]).cuda().repeat(4, 1, 1).contiguous()
-for lanes in sys.argv[1:] or ["0", "1"]:
+for lanes in sys.argv[1:] or ["0", "1", "2"]:
     os.environ["FIMEX_AMD_SUM_ALGO"] = lanes
     best = 1e9
     for rep in range(3):
@@ -21,7 +21,7 @@ for lanes in sys.argv[1:] or ["0", "1"]:
         best = min(best, time.perf_counter() - t0)
     print(json.dumps({"sum_algo": int(lanes), "ms_one_sweep_call": best * 1e3}), flush=True)
 x = d0[0].contiguous().view(-1)
-for algo in (0, 1):
+for algo in (0, 1, 2):
     for mode, avg in ((0, 0.0), (1, 280.0)):
         best = 1e9
         for rep in range(3):

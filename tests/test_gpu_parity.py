@@ -253,6 +253,24 @@ def test_creepfill_matches_oracle(fa, shape, params):
         assert cases.same(gotv[z], wantv), "slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))
 
 
+@pytest.mark.parametrize("algo", ["0", "1", "2"], ids=["add_chain", "one_workgroup", "whole_chip"])
+def test_fills_with_each_evaluation_of_the_sums(fa, monkeypatch, algo):
+    """The first-guess sums (mean, mean absolute deviation) as an add chain, binade-parallel in one workgroup per slice
+    (batches of 100 slices and more) and binade-parallel over the whole chip (smaller batches): the same bits."""
+    monkeypatch.setenv("FIMEX_AMD_SUM_ALGO", algo)
+    f = cases.holes(3, 170, 260, seed=91)
+    got, nch = fa.fill2d_host(f, 4.0, 1.6, 30)
+    gotc, nchc = fa.creepfill2d_host(f, 3, 2)
+    gotv, _ = fa.creepfillval2d_host(f, 271.25, 3, 2)
+    for z in range(3):
+        want, wn, _ = oracle.fill2d(f[z], 4.0, 1.6, 30)
+        assert nch[z] == wn and cases.same(got[z], want), cases.describe_mismatch(got[z], want)
+        wantc, wnc, _ = oracle.creepfill2d(f[z], 3, 2)
+        assert nchc[z] == wnc and cases.same(gotc[z], wantc)
+        wantv, _, _ = oracle.creepfillval2d(f[z], 271.25, 3, 2)
+        assert cases.same(gotv[z], wantv)
+
+
 def test_fill2d_both_kernels_agree(fa, monkeypatch):
     """The systolic row-band kernel and the anti-diagonal wavefront kernel are two implementations of the same order."""
     f = cases.holes(2, 150, 210, seed=77)
@@ -330,7 +348,7 @@ def test_scan_order_sums_equal_the_sequential_loop(fa, kind, n):
     avg = want0 / d.size if d.size else 0.0
     want1 = _seq_sum(np.abs(d - avg))
     t = torch.from_numpy(x).cuda()
-    for algo in (0, 1):
+    for algo in (0, 1, 2):  # add chain, binade-parallel in one workgroup, the same over the whole chip
         s0, u0 = fa.scan_sum_device(t.data_ptr(), n, 0, 0.0, algo)
         s1, u1 = fa.scan_sum_device(t.data_ptr(), n, 1, avg, algo)
         s2, u2 = fa.scan_sum_device(t.data_ptr(), n, 2, 0.0, algo)

@@ -5,7 +5,7 @@
 // PROJ.4 is a third-party library that is not part of the reference tree; the projections are implemented from their
 // published closed forms on the sphere (Snyder, "Map Projections - A Working Manual", USGS PP 1395) with PROJ.4's
 // conventions at the pj_transform boundary: geographic coordinates in radians, projected x = a * x' + x_0, longitudes
-// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, ob_tran +
+// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, ob_tran +
 // o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
 // an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
@@ -30,7 +30,7 @@ constexpr double kSpi = 3.14159265359;  // PROJ.4's adjlon threshold
 constexpr double kEps10 = 1e-10;
 constexpr double kDegToRad = .0174532925199432958;  // proj_api.h DEG_TO_RAD
 
-enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc };
+enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea };
 enum StereMode { kNorth = 0, kSouth, kOblique, kEquatorial };
 
 struct ProjParams {
@@ -41,6 +41,7 @@ struct ProjParams {
     double lamp, sphip, cphip;    // ob_tran
     double esp, ml0, en[5];       // tmerc
     double Qn, Zb, cgb[6], cbg[6], utg[6], gtu[6];  // etmerc
+    double qp, rq, dd, xmf, ymf, sinb1, cosb1, apa[3];  // laea
     double towgs84[7];            // only compared between the two sides
 };
 
@@ -59,6 +60,15 @@ __host__ __device__ inline double tsfn(double phi, double sinphi, double e)
     return tan(.5 * (kHalfPi - phi)) / pow((1. - sinphi) / (1. + sinphi), .5 * e);
 }
 __host__ __device__ inline double msfn(double sinphi, double cosphi, double es) { return cosphi / sqrt(1. - es * sinphi * sinphi); }
+// pj_qsfn (Snyder eq. 3-12)
+__host__ __device__ inline double qsfn(double sinphi, double e, double one_es)
+{
+    if (e >= 1e-7) {
+        const double con = e * sinphi;
+        return one_es * (sinphi / (1. - con * con) - (.5 / e) * log((1. - con) / (1. + con)));
+    }
+    return sinphi + sinphi;
+}
 __host__ __device__ inline double ssfn(double phit, double sinphi, double e)
 {
     sinphi *= e;
@@ -368,6 +378,40 @@ ProjParams parse_proj4(const char* text)
             p.esp = p.k0;
             p.ml0 = .5 * p.esp;
         }
+    } else if (name == "laea") {  // PJ_laea.c setup
+        p.kind = kLaea;
+        const double t = std::fabs(p.phi0);
+        if (std::fabs(t - kHalfPi) < kEps10) p.mode = p.phi0 < 0 ? kSouth : kNorth;
+        else p.mode = t < kEps10 ? kEquatorial : kOblique;
+        if (p.es != 0) {
+            const double one_es = 1. - p.es;
+            p.qp = qsfn(1., p.e, one_es);
+            double t2 = p.es * p.es;  // pj_authset
+            p.apa[0] = p.es * .33333333333333333333 + t2 * .17222222222222222222;
+            p.apa[1] = t2 * .06388888888888888888;
+            t2 *= p.es;
+            p.apa[0] += t2 * .10257936507936507936;
+            p.apa[1] += t2 * .06640211640211640211;
+            p.apa[2] = t2 * .01641501294219154443;
+            if (p.mode == kNorth || p.mode == kSouth) p.dd = 1.;
+            else if (p.mode == kEquatorial) {
+                p.rq = std::sqrt(.5 * p.qp);
+                p.dd = 1. / p.rq;
+                p.xmf = 1.;
+                p.ymf = .5 * p.qp;
+            } else {
+                p.rq = std::sqrt(.5 * p.qp);
+                const double sinphi = std::sin(p.phi0);
+                p.sinb1 = qsfn(sinphi, p.e, one_es) / p.qp;
+                p.cosb1 = std::sqrt(1. - p.sinb1 * p.sinb1);
+                p.dd = std::cos(p.phi0) / (std::sqrt(1. - p.es * sinphi * sinphi) * p.rq * p.cosb1);
+                p.ymf = (p.xmf = p.rq) / p.dd;
+                p.xmf *= p.dd;
+            }
+        } else if (p.mode == kOblique) {
+            p.sinb1 = std::sin(p.phi0);
+            p.cosb1 = std::cos(p.phi0);
+        }
     } else if (name == "ob_tran") {
         p.kind = kObTran;
         if (p.es != 0) throw Error("ob_tran is implemented on the sphere only: " + proj4);
@@ -470,6 +514,61 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
                 py = b >= 1. ? 0. : acos(py);
                 if (phi < 0.) py = -py;
                 py = p.esp * (py - p.phi0);
+            }
+        }
+    } else if (p.kind == kLaea) {  // PJ_laea.c e_forward / s_forward
+        double coslam = cos(lam);
+        const double sinlam = sin(lam), sinphi = sin(phi);
+        if (p.es != 0) {
+            double q = qsfn(sinphi, p.e, 1. - p.es), b;
+            if (p.mode == kOblique || p.mode == kEquatorial) {
+                const double sinb = q / p.qp, cosb = sqrt(1. - sinb * sinb);
+                if (p.mode == kOblique) {
+                    b = 1. + p.sinb1 * sinb + p.cosb1 * cosb * coslam;
+                    if (fabs(b) < kEps10) { px = NAN; py = NAN; }
+                    else {
+                        b = sqrt(2. / b);
+                        py = p.ymf * b * (p.cosb1 * sinb - p.sinb1 * cosb * coslam);
+                        px = p.xmf * b * cosb * sinlam;
+                    }
+                } else {
+                    b = 1. + cosb * coslam;
+                    if (fabs(b) < kEps10) { px = NAN; py = NAN; }
+                    else {
+                        b = sqrt(2. / b);
+                        py = b * sinb * p.ymf;
+                        px = p.xmf * b * cosb * sinlam;
+                    }
+                }
+            } else {
+                if (p.mode == kNorth) { b = kHalfPi + phi; q = p.qp - q; }
+                else { b = phi - kHalfPi; q = p.qp + q; }
+                if (fabs(b) < kEps10) { px = NAN; py = NAN; }
+                else if (q >= 0.) {
+                    b = sqrt(q);
+                    px = b * sinlam;
+                    py = coslam * (p.mode == kSouth ? b : -b);
+                } else { px = 0.; py = 0.; }
+            }
+        } else {
+            const double cosphi = cos(phi);
+            if (p.mode == kEquatorial || p.mode == kOblique) {
+                py = p.mode == kEquatorial ? 1. + cosphi * coslam : 1. + p.sinb1 * sinphi + p.cosb1 * cosphi * coslam;
+                if (py <= kEps10) { px = NAN; py = NAN; }
+                else {
+                    py = sqrt(2. / py);
+                    px = py * cosphi * sinlam;
+                    py *= p.mode == kEquatorial ? sinphi : p.cosb1 * sinphi - p.sinb1 * cosphi * coslam;
+                }
+            } else {
+                if (p.mode == kNorth) coslam = -coslam;
+                if (fabs(phi + p.phi0) < kEps10) { px = NAN; py = NAN; }
+                else {
+                    py = kFortPi - phi * .5;
+                    py = 2. * (p.mode == kSouth ? cos(py) : sin(py));
+                    px = py * sinlam;
+                    py *= coslam;
+                }
             }
         }
     } else if (p.kind == kEtmerc) {  // PJ_etmerc.c e_forward
@@ -604,6 +703,67 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
             phi = asin(sqrt((1. - h * h) / (1. + g * g)));
             if (ys < 0. && -phi + p.phi0 < 0.) phi = -phi;  // the hemisphere test of PROJ 4.9 (4.8 and older: y < 0 alone, wrong for lat_0 != 0)
             lam = (g != 0. || h != 0.) ? atan2(g, h) : 0.;
+        }
+    } else if (p.kind == kLaea) {  // PJ_laea.c e_inverse / s_inverse
+        if (p.es != 0) {
+            double ab = 0;
+            bool centre = false;
+            if (p.mode == kEquatorial || p.mode == kOblique) {
+                xs /= p.dd;
+                ys *= p.dd;
+                const double rho = hypot(xs, ys);
+                if (rho < kEps10) centre = true;
+                else {
+                    double sCe = 2. * asin(.5 * rho / p.rq);
+                    const double cCe = cos(sCe);
+                    sCe = sin(sCe);
+                    xs *= sCe;
+                    if (p.mode == kOblique) {
+                        ab = cCe * p.sinb1 + ys * sCe * p.cosb1 / rho;
+                        ys = rho * p.cosb1 * cCe - ys * p.sinb1 * sCe;
+                    } else {
+                        ab = ys * sCe / rho;
+                        ys = rho * cCe;
+                    }
+                }
+            } else {
+                if (p.mode == kNorth) ys = -ys;
+                const double q = xs * xs + ys * ys;
+                if (q == 0.) centre = true;
+                else {
+                    ab = 1. - q / p.qp;
+                    if (p.mode == kSouth) ab = -ab;
+                }
+            }
+            if (centre) { lam = 0.; phi = p.phi0; }
+            else {
+                lam = atan2(xs, ys);
+                const double beta = asin(ab), t = beta + beta;  // pj_authlat
+                phi = beta + p.apa[0] * sin(t) + p.apa[1] * sin(t + t) + p.apa[2] * sin(t + t + t);
+            }
+        } else {
+            const double rh = hypot(xs, ys);
+            phi = rh * .5;
+            if (phi > 1.) { phi = NAN; lam = NAN; }
+            else {
+                phi = 2. * asin(phi);
+                const double sinz = sin(phi), cosz = cos(phi);
+                if (p.mode == kEquatorial) {
+                    phi = fabs(rh) <= kEps10 ? 0. : asin(ys * sinz / rh);
+                    xs *= sinz;
+                    ys = cosz * rh;
+                } else if (p.mode == kOblique) {
+                    phi = fabs(rh) <= kEps10 ? p.phi0 : asin(cosz * p.sinb1 + ys * sinz * p.cosb1 / rh);
+                    xs *= sinz * p.cosb1;
+                    ys = (cosz - sin(phi) * p.sinb1) * rh;
+                } else if (p.mode == kNorth) {
+                    ys = -ys;
+                    phi = kHalfPi - phi;
+                } else {
+                    phi -= kHalfPi;
+                }
+                lam = (ys == 0. && (p.mode == kEquatorial || p.mode == kOblique)) ? 0. : atan2(xs, ys);
+            }
         }
     } else if (p.kind == kEtmerc) {  // PJ_etmerc.c e_inverse
         double Cn = (ys - p.Zb) / p.Qn, Ce = xs / p.Qn;

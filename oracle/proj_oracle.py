@@ -13,7 +13,7 @@ Lambert conformal conic eq. 15-1..15-5; oblique transformation eq. 5-7..5-10b)
 with PROJ.4's conventions: longitude/latitude in radians at the pj_transform
 boundary, x = a*x' + x_0, lam = lon - lon_0 wrapped to [-pi, pi].
 Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered for
-merc, lcc, polar and oblique stere, tmerc and utm (the UTM zone 33 / WGS84 string
+merc, lcc, polar and oblique stere, laea, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
 of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
 latitude pass unchanged between the two sides (no datum shift is restated; a pair
@@ -222,7 +222,7 @@ class _Proj:
     def _kind(self):
         if self.latlong:
             return "latlong"
-        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm"):
+        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea"):
             return self.name
         raise NotImplementedError("projection %s" % self.name)
 
@@ -566,6 +566,138 @@ class _Proj:
 
     def _inv_utm(self, x, y):
         return self._inv_etmerc(x, y)
+
+    # ---- Lambert azimuthal equal-area (Snyder eq. 24-2..24-26, 3-11..3-18; authalic latitude series 3-18 to e^6)
+    def _qsfn(self, sinphi):
+        if self.e >= 1e-7:
+            con = self.e * sinphi
+            return (1. - self.es) * (sinphi / (1. - con * con) - (.5 / self.e) * np.log((1. - con) / (1. + con)))
+        return sinphi + sinphi
+
+    def _setup_laea(self):
+        t = abs(self.phi0)
+        if abs(t - HALFPI) < _EPS10:
+            self.mode = "S" if self.phi0 < 0 else "N"
+        else:
+            self.mode = "E" if t < _EPS10 else "O"
+        if self.es != 0.:
+            es = self.es
+            self.qp = float(self._qsfn(1.))
+            # pj_authset: Snyder's series 3-18 with PROJ.4's constants (its last one, .0164150..., is not Snyder's 761/45360)
+            self.apa = [es * .33333333333333333333 + es * es * .17222222222222222222 + es ** 3 * .10257936507936507936,
+                        es * es * .06388888888888888888 + es ** 3 * .06640211640211640211, es ** 3 * .01641501294219154443]
+            if self.mode in ("N", "S"):
+                self.dd = 1.
+            elif self.mode == "E":
+                self.rq = math.sqrt(.5 * self.qp)
+                self.dd = 1. / self.rq
+                self.xmf, self.ymf = 1., .5 * self.qp
+            else:
+                self.rq = math.sqrt(.5 * self.qp)
+                sinphi = math.sin(self.phi0)
+                self.sinb1 = float(self._qsfn(sinphi)) / self.qp
+                self.cosb1 = math.sqrt(1. - self.sinb1 * self.sinb1)
+                self.dd = math.cos(self.phi0) / (math.sqrt(1. - es * sinphi * sinphi) * self.rq * self.cosb1)
+                self.xmf = self.rq * self.dd
+                self.ymf = self.rq / self.dd
+        elif self.mode == "O":
+            self.sinb1, self.cosb1 = math.sin(self.phi0), math.cos(self.phi0)
+
+    def _fwd_laea(self, lam, phi):
+        coslam, sinlam, sinphi = np.cos(lam), np.sin(lam), np.sin(phi)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.es != 0.:
+                q = self._qsfn(sinphi)
+                if self.mode in ("O", "E"):
+                    sinb = q / self.qp
+                    cosb = np.sqrt(1. - sinb * sinb)
+                    if self.mode == "O":
+                        b = 1. + self.sinb1 * sinb + self.cosb1 * cosb * coslam
+                        bb = np.sqrt(2. / b)
+                        y = self.ymf * bb * (self.cosb1 * sinb - self.sinb1 * cosb * coslam)
+                    else:
+                        b = 1. + cosb * coslam
+                        bb = np.sqrt(2. / b)
+                        y = bb * sinb * self.ymf
+                    x = self.xmf * bb * cosb * sinlam
+                    bad = np.abs(b) < _EPS10
+                else:
+                    if self.mode == "N":
+                        b, q = HALFPI + phi, self.qp - q
+                    else:
+                        b, q = phi - HALFPI, self.qp + q
+                    bb = np.sqrt(np.where(q >= 0., q, 0.))
+                    x = np.where(q >= 0., bb * sinlam, 0.)
+                    y = np.where(q >= 0., coslam * (bb if self.mode == "S" else -bb), 0.)
+                    bad = np.abs(b) < _EPS10
+                return np.where(bad, np.nan, x), np.where(bad, np.nan, y)
+            cosphi = np.cos(phi)
+            if self.mode in ("E", "O"):
+                y = 1. + cosphi * coslam if self.mode == "E" else 1. + self.sinb1 * sinphi + self.cosb1 * cosphi * coslam
+                bad = y <= _EPS10
+                k = np.sqrt(2. / y)
+                x = k * cosphi * sinlam
+                y = k * (sinphi if self.mode == "E" else self.cosb1 * sinphi - self.sinb1 * cosphi * coslam)
+            else:
+                if self.mode == "N":
+                    coslam = -coslam
+                bad = np.abs(phi + self.phi0) < _EPS10
+                y = FORTPI - phi * .5
+                y = 2. * (np.cos(y) if self.mode == "S" else np.sin(y))
+                x = y * sinlam
+                y = y * coslam
+            return np.where(bad, np.nan, x), np.where(bad, np.nan, y)
+
+    def _inv_laea(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.es != 0.:
+                if self.mode in ("E", "O"):
+                    x = x / self.dd
+                    y = y * self.dd
+                    rho = np.hypot(x, y)
+                    sCe = 2. * np.arcsin(.5 * rho / self.rq)
+                    cCe, sCe = np.cos(sCe), np.sin(sCe)
+                    x = x * sCe
+                    if self.mode == "O":
+                        ab = cCe * self.sinb1 + y * sCe * self.cosb1 / rho
+                        y = rho * self.cosb1 * cCe - y * self.sinb1 * sCe
+                    else:
+                        ab = y * sCe / rho
+                        y = rho * cCe
+                    centre = rho < _EPS10
+                else:
+                    if self.mode == "N":
+                        y = -y
+                    q = x * x + y * y
+                    ab = 1. - q / self.qp
+                    if self.mode == "S":
+                        ab = -ab
+                    centre = q == 0.
+                beta = np.arcsin(ab)
+                t = beta + beta
+                phi = beta + self.apa[0] * np.sin(t) + self.apa[1] * np.sin(t + t) + self.apa[2] * np.sin(t + t + t)
+                lam = np.arctan2(x, y)
+                return np.where(centre, 0., lam), np.where(centre, self.phi0, phi)
+            rh = np.hypot(x, y)
+            phi = rh * .5
+            bad = phi > 1.
+            phi = 2. * np.arcsin(np.clip(phi, -1., 1.))
+            sinz, cosz = np.sin(phi), np.cos(phi)
+            if self.mode == "E":
+                phi = np.where(np.abs(rh) <= _EPS10, 0., np.arcsin(y * sinz / rh))
+                x = x * sinz
+                y = cosz * rh
+            elif self.mode == "O":
+                phi = np.where(np.abs(rh) <= _EPS10, self.phi0, np.arcsin(cosz * self.sinb1 + y * sinz * self.cosb1 / rh))
+                x = x * sinz * self.cosb1
+                y = (cosz - np.sin(phi) * self.sinb1) * rh
+            elif self.mode == "N":
+                y = -y
+                phi = HALFPI - phi
+            else:
+                phi = phi - HALFPI
+            lam = np.where((y == 0.) & (self.mode in ("E", "O")), 0., np.arctan2(x, y))
+            return np.where(bad, np.nan, lam), np.where(bad, np.nan, phi)
 
     # ---- general oblique transformation around a geographic "projection" (rotated pole)
     def _setup_ob_tran(self):

@@ -25,7 +25,9 @@ LCC = "+proj=lcc +lat_0=63 +lon_0=15 +lat_1=63 +lat_2=63 +no_defs +R=6.371e+06"
 LCC2 = "+proj=lcc +lat_0=48 +lon_0=8 +lat_1=30 +lat_2=60 +R=6371229"
 MERC = "+proj=merc +lon_0=5 +lat_ts=30 +R=6371000"
 ROT = "+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06 +no_defs"
-ALL = [GEO, STERE, STERE_OBL, STERE_EQ, STERE_S, LCC, LCC2, MERC, ROT]
+LAEA_S = "+proj=laea +lat_0=52 +lon_0=10 +R=6371000"
+LAEA_SP = "+proj=laea +lat_0=90 +lon_0=-30 +R=6371000 +x_0=100"
+ALL = [GEO, STERE, STERE_OBL, STERE_EQ, STERE_S, LCC, LCC2, MERC, ROT, LAEA_S, LAEA_SP]
 # on an ellipsoid (the UTM string is the one of test/testInterpolator.cc:422)
 GEO_W = "+proj=latlong +datum=WGS84"
 UTM33 = "+proj=utm +zone=33 +datum=WGS84 +no_defs"
@@ -40,7 +42,10 @@ STERE_WO = "+proj=stere +lat_0=52.156 +lon_0=5.387 +k=0.9999079 +x_0=155000 +y_0
 LCC_W = "+proj=lcc +lat_0=52 +lon_0=10 +lat_1=35 +lat_2=65 +x_0=4000000 +y_0=2800000 +ellps=GRS80"
 LCC_W1 = "+proj=lcc +lat_0=63 +lon_0=15 +lat_1=63 +a=6378137 +rf=298.257223563"
 MERC_W = "+proj=merc +lon_0=5 +lat_ts=30 +ellps=WGS84"
-ELLIPSOIDAL = [UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
+LAEA_W = "+proj=laea +lat_0=52 +lon_0=10 +x_0=4321000 +y_0=3210000 +ellps=GRS80"   # ETRS89-LAEA
+LAEA_WP = "+proj=laea +lat_0=90 +lon_0=0 +ellps=WGS84"
+LAEA_WE = "+proj=laea +lat_0=0 +lon_0=20 +ellps=WGS84"
+ELLIPSOIDAL = [LAEA_W, LAEA_WP, LAEA_WE, UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
 
 
 @pytest.fixture(scope="module")
@@ -95,7 +100,7 @@ def test_ellipsoidal_projections_from_geographic_and_back(fa, dst):
     lon0 = np.degrees(po._Proj(dst).lam0)
     lon = np.radians(rng.uniform(lon0 - 12, lon0 + 12, 20000) if series else (rng.uniform(lon0 - 40, lon0 + 40, 20000) if tm else rng.uniform(-60, 80, 20000)))
     south = dst == STERE_WS
-    lat = np.radians(rng.uniform(-85 if south else (-70 if tm or dst == MERC_W else 20), -30 if south else 85, 20000))
+    lat = np.radians(rng.uniform(-85 if south else (-70 if tm or dst in (MERC_W, LAEA_WE) else 20), -30 if south else 85, 20000))
     x, y = fa.project_values_host(GEO_W, dst, lon, lat)
     wx, wy = po.transform(GEO_W, dst, lon, lat)
     atol = 2e-6 if dst == TMERC_S else 2e-8   # metres; the spherical form takes acos of nearly 1 at the equator
@@ -103,7 +108,7 @@ def test_ellipsoidal_projections_from_geographic_and_back(fa, dst):
     bx, by = fa.project_values_host(dst, GEO_W, x, y)
     wbx, wby = po.transform(dst, GEO_W, x, y)
     np.testing.assert_allclose(bx, wbx, atol=2e-13); np.testing.assert_allclose(by, wby, atol=2e-13)
-    tol = 2e-7 if series else 2e-10  # the truncated series does not invert itself exactly away from the meridian
+    tol = 2e-7 if series else (1e-9 if "laea" in dst else 2e-10)  # truncated series do not invert themselves exactly
     np.testing.assert_allclose(bx, lon, atol=tol); np.testing.assert_allclose(by, lat, atol=tol)
     assert not fa.projection_is_degree(dst)
 

@@ -299,7 +299,22 @@ SNYDER = [
     ("+proj=lcc +ellps=clrk66 +lat_1=33 +lat_2=45 +lat_0=23 +lon_0=-96", (-75., 35.), (1894410.9, 1564649.5)),
     ("+proj=stere +ellps=intl +lat_0=-90 +lat_ts=-71 +lon_0=-100", (150., -75.), (-1540033.6, -560526.4)),
     ("+proj=stere +ellps=clrk66 +lat_0=40 +lon_0=-100 +k=0.9999", (-90., 30.), (971630.8, -1063049.3)),
+    ("+proj=laea +ellps=clrk66 +lat_0=40 +lon_0=-100", (-110., 30.), (-965932.1, -1056814.9)),
 ]
+
+
+def test_lambert_azimuthal_equal_area_worked_examples():
+    """Snyder's other two examples for the projection: the sphere of radius 3, and the polar aspect on the International ellipsoid."""
+    x, y = po.transform("+proj=latlong +R=3", "+proj=laea +R=3 +lat_0=40 +lon_0=-100", np.radians([100.]), np.radians([-20.]))
+    assert abs(x[0] + 4.2339303) < 1e-7 and abs(y[0] - 4.0257775) < 1e-7
+    x, y = po.transform("+proj=latlong +ellps=intl", "+proj=laea +ellps=intl +lat_0=90 +lon_0=-100", np.radians([5.]), np.radians([80.]))
+    assert abs(x[0] - 1077459.7) < 0.1 and abs(y[0] - 288704.5) < 0.1
+    rng = np.random.default_rng(2)
+    lon, lat = np.radians(rng.uniform(-40, 60, 500)), np.radians(rng.uniform(15, 85, 500))
+    for proj in ("+proj=laea +lat_0=52 +lon_0=10 +x_0=4321000 +y_0=3210000 +ellps=GRS80", "+proj=laea +lat_0=90 +ellps=WGS84",
+                 "+proj=laea +lat_0=0 +lon_0=20 +ellps=WGS84", "+proj=laea +lat_0=52 +lon_0=10 +R=6371000", "+proj=laea +lat_0=90 +R=6371000"):
+        bl, bp = po.transform(proj, "+proj=latlong +ellps=WGS84", *po.transform("+proj=latlong +ellps=WGS84", proj, lon, lat))
+        np.testing.assert_allclose(bl, lon, atol=1e-12); np.testing.assert_allclose(bp, lat, atol=5e-10)  # three-term authalic series
 
 
 @pytest.mark.parametrize("proj,lonlat,xy", SNYDER)

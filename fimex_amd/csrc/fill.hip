@@ -336,10 +336,11 @@ __device__ __forceinline__ bool sum_slice_active(const SumJob& j, uint32_t slice
     return true;
 }
 
-__global__ void __launch_bounds__(kBlock) sum_approx_kernel(SumJob j, SumWork w)
+// (grids of the per-chunk kernels are flat: blocks of a slice, then the next slice -- gridDim.y stops at 65535 slices)
+__global__ void __launch_bounds__(kBlock) sum_approx_kernel(SumJob j, SumWork w, uint32_t blocksPerSlice)
 {
-    const uint32_t lane = threadIdx.x & (kWave - 1), slice = blockIdx.y;
-    const size_t c = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1), slice = blockIdx.x / blocksPerSlice;
+    const size_t c = (size_t)(blockIdx.x % blocksPerSlice) * (kBlock / kWave) + threadIdx.x / kWave;
     double average;
     if (c >= w.nChunks || !sum_slice_active(j, slice, average)) return;
     const float* f = j.values + (size_t)slice * j.total;
@@ -388,10 +389,10 @@ __global__ void __launch_bounds__(kFillBlock) sum_predict_kernel(SumJob j, SumWo
     }
 }
 
-__global__ void __launch_bounds__(kBlock) sum_eval_kernel(SumJob j, SumWork w)
+__global__ void __launch_bounds__(kBlock) sum_eval_kernel(SumJob j, SumWork w, uint32_t blocksPerSlice)
 {
-    const uint32_t lane = threadIdx.x & (kWave - 1), slice = blockIdx.y;
-    const size_t c = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1), slice = blockIdx.x / blocksPerSlice;
+    const size_t c = (size_t)(blockIdx.x % blocksPerSlice) * (kBlock / kWave) + threadIdx.x / kWave;
     double average;
     if (c >= w.nChunks || !sum_slice_active(j, slice, average)) return;
     const size_t idx = (size_t)slice * w.nChunks + c;
@@ -519,11 +520,13 @@ struct SumBuffers {
 
 void launch_chip_sum(const SumJob& j, const SumBuffers& b, size_t slices, const StitchOut& o, hipStream_t stream)
 {
-    const dim3 perChunk((uint32_t)ceil_div(b.work.nChunks, (size_t)(kBlock / kWave)), (uint32_t)slices);
-    sum_approx_kernel<<<perChunk, kBlock, 0, stream>>>(j, b.work);
+    const size_t blocksPerSlice = ceil_div(b.work.nChunks, (size_t)(kBlock / kWave));
+    FA_REQUIRE(blocksPerSlice * slices <= 0x7FFFFFFFull, "too many slices for one call");
+    const dim3 perChunk((uint32_t)(blocksPerSlice * slices));
+    sum_approx_kernel<<<perChunk, kBlock, 0, stream>>>(j, b.work, (uint32_t)blocksPerSlice);
     if (j.mode != 2) {
         sum_predict_kernel<<<dim3((uint32_t)slices), kFillBlock, 0, stream>>>(j, b.work);
-        sum_eval_kernel<<<perChunk, kBlock, 0, stream>>>(j, b.work);
+        sum_eval_kernel<<<perChunk, kBlock, 0, stream>>>(j, b.work, (uint32_t)blocksPerSlice);
     }
     sum_stitch_kernel<<<dim3((uint32_t)slices), kWave, 0, stream>>>(j, b.work, o);
     FA_HIP(hipGetLastError());
@@ -721,6 +724,7 @@ struct FirstGuessArgs {
     unsigned char* mbRows;    // fill2d: [nz][2][nx] NaN mask of row 0 and row ny - 1
     unsigned char* mbCols;    // fill2d: [nz][2][ny] NaN mask of column 0 and column nx - 1
     uint32_t nx, ny, mws;
+    uint32_t blocksPerSlice;
 };
 
 // One wave per row: undefined cells take the first guess (:1288-1299, :1408-1421) and the mask words are written in the
@@ -728,17 +732,18 @@ struct FirstGuessArgs {
 template <bool CREEP>
 __global__ void __launch_bounds__(kBlock) first_guess_kernel(FirstGuessArgs a)
 {
-    const SliceStats st = a.stats[blockIdx.y];
+    const uint32_t slice = blockIdx.x / a.blocksPerSlice;  // flat grid: gridDim.y stops at 65535 slices
+    const SliceStats st = a.stats[slice];
     if (st.skip) return;
     const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t y = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const uint32_t y = (blockIdx.x % a.blocksPerSlice) * (kBlock / kWave) + threadIdx.x / kWave;
     if (y >= ny) return;
     const float guess = (float)st.average;
-    float* row = a.field + ((size_t)blockIdx.y * ny + y) * nx;
+    float* row = a.field + ((size_t)slice * ny + y) * nx;
     const bool edgeRow = y == 0 || y == ny - 1;
     if (!CREEP && edgeRow) {
-        unsigned char* mb = a.mbRows + ((size_t)blockIdx.y * 2 + (y == 0 ? 0 : 1)) * nx;
+        unsigned char* mb = a.mbRows + ((size_t)slice * 2 + (y == 0 ? 0 : 1)) * nx;
         for (uint32_t x = lane; x < nx; x += kWave) {
             const bool u = isnan(row[x]);
             mb[x] = u;
@@ -747,8 +752,8 @@ __global__ void __launch_bounds__(kBlock) first_guess_kernel(FirstGuessArgs a)
         return;
     }
     const uint32_t l = edgeRow ? 0u : ((y - 1) & (kWave - 1));
-    uint32_t* mrow = a.mask + ((size_t)blockIdx.y * ny + y) * mws;
-    unsigned char* mbLeft = CREEP ? nullptr : a.mbCols + (size_t)blockIdx.y * 2 * ny;
+    uint32_t* mrow = a.mask + ((size_t)slice * ny + y) * mws;
+    unsigned char* mbLeft = CREEP ? nullptr : a.mbCols + (size_t)slice * 2 * ny;
     constexpr int kAhead = 8;
     for (uint32_t base0 = 0; base0 < mws * 32; base0 += kAhead * kWave) {
         float v[kAhead];
@@ -822,7 +827,10 @@ void launch_fill_prologue(bool creep, float* d_field, SliceStats* d_stats, size_
     g.nx = (uint32_t)nx;
     g.ny = (uint32_t)ny;
     g.mws = mws;
-    const dim3 grid((uint32_t)ceil_div(ny, (size_t)(kBlock / kWave)), (uint32_t)nz);
+    const size_t rowBlocks = ceil_div(ny, (size_t)(kBlock / kWave));
+    FA_REQUIRE(rowBlocks * nz <= 0x7FFFFFFFull, "too many slices for one call");
+    g.blocksPerSlice = (uint32_t)rowBlocks;
+    const dim3 grid((uint32_t)(rowBlocks * nz));
     if (creep) first_guess_kernel<true><<<grid, kBlock, 0, stream>>>(g);
     else first_guess_kernel<false><<<grid, kBlock, 0, stream>>>(g);
     FA_HIP(hipGetLastError());

@@ -5,7 +5,7 @@
 // PROJ.4 is a third-party library that is not part of the reference tree; the projections are implemented from their
 // published closed forms on the sphere (Snyder, "Map Projections - A Working Manual", USGS PP 1395) with PROJ.4's
 // conventions at the pj_transform boundary: geographic coordinates in radians, projected x = a * x' + x_0, longitudes
-// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, ob_tran +
+// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, ob_tran +
 // o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
 // an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
@@ -30,7 +30,7 @@ constexpr double kSpi = 3.14159265359;  // PROJ.4's adjlon threshold
 constexpr double kEps10 = 1e-10;
 constexpr double kDegToRad = .0174532925199432958;  // proj_api.h DEG_TO_RAD
 
-enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea };
+enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea };
 enum StereMode { kNorth = 0, kSouth, kOblique, kEquatorial };
 
 struct ProjParams {
@@ -41,7 +41,8 @@ struct ProjParams {
     double lamp, sphip, cphip;    // ob_tran
     double esp, ml0, en[5];       // tmerc
     double Qn, Zb, cgb[6], cbg[6], utg[6], gtu[6];  // etmerc
-    double qp, rq, dd, xmf, ymf, sinb1, cosb1, apa[3];  // laea
+    double qp, rq, dd, xmf, ymf, sinb1, cosb1, apa[3];  // laea (aea: dd, and n, c, rho0 of lcc)
+    double ec, n2;                // aea
     double towgs84[7];            // only compared between the two sides
 };
 
@@ -378,6 +379,33 @@ ProjParams parse_proj4(const char* text)
             p.esp = p.k0;
             p.ml0 = .5 * p.esp;
         }
+    } else if (name == "aea") {  // PJ_aea.c setup
+        p.kind = kAea;
+        const double phi1 = rad("lat_1", 0), phi2 = rad("lat_2", 0);
+        if (std::fabs(phi1 + phi2) < kEps10) throw Error("aea: lat_1 = -lat_2: " + proj4);
+        double sinphi = std::sin(phi1), cosphi = std::cos(phi1);
+        p.n = sinphi;
+        const bool secant = std::fabs(phi1 - phi2) >= kEps10;
+        if (p.es != 0) {
+            const double one_es = 1. - p.es;
+            const double m1 = msfn(sinphi, cosphi, p.es), ml1 = qsfn(sinphi, p.e, one_es);
+            if (secant) {
+                sinphi = std::sin(phi2);
+                cosphi = std::cos(phi2);
+                const double m2 = msfn(sinphi, cosphi, p.es), ml2 = qsfn(sinphi, p.e, one_es);
+                p.n = (m1 * m1 - m2 * m2) / (ml2 - ml1);
+            }
+            p.ec = 1. - .5 * one_es * std::log((1. - p.e) / (1. + p.e)) / p.e;
+            p.c = m1 * m1 + p.n * ml1;
+            p.dd = 1. / p.n;
+            p.rho0 = p.dd * std::sqrt(p.c - p.n * qsfn(std::sin(p.phi0), p.e, one_es));
+        } else {
+            if (secant) p.n = .5 * (p.n + std::sin(phi2));
+            p.n2 = p.n + p.n;
+            p.c = cosphi * cosphi + p.n2 * sinphi;
+            p.dd = 1. / p.n;
+            p.rho0 = p.dd * std::sqrt(p.c - p.n2 * std::sin(p.phi0));
+        }
     } else if (name == "laea") {  // PJ_laea.c setup
         p.kind = kLaea;
         const double t = std::fabs(p.phi0);
@@ -515,6 +543,15 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
                 if (phi < 0.) py = -py;
                 py = p.esp * (py - p.phi0);
             }
+        }
+    } else if (p.kind == kAea) {  // PJ_aea.c e_forward
+        double rho = p.c - (p.es != 0 ? p.n * qsfn(sin(phi), p.e, 1. - p.es) : p.n2 * sin(phi));
+        if (rho < 0.) { px = NAN; py = NAN; }
+        else {
+            rho = p.dd * sqrt(rho);
+            lam *= p.n;
+            px = rho * sin(lam);
+            py = p.rho0 - rho * cos(lam);
         }
     } else if (p.kind == kLaea) {  // PJ_laea.c e_forward / s_forward
         double coslam = cos(lam);
@@ -703,6 +740,34 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
             phi = asin(sqrt((1. - h * h) / (1. + g * g)));
             if (ys < 0. && -phi + p.phi0 < 0.) phi = -phi;  // the hemisphere test of PROJ 4.9 (4.8 and older: y < 0 alone, wrong for lat_0 != 0)
             lam = (g != 0. || h != 0.) ? atan2(g, h) : 0.;
+        }
+    } else if (p.kind == kAea) {  // PJ_aea.c e_inverse
+        ys = p.rho0 - ys;
+        double rho = hypot(xs, ys);
+        if (rho != 0.) {
+            if (p.n < 0.) { rho = -rho; xs = -xs; ys = -ys; }
+            phi = rho / p.dd;
+            if (p.es != 0) {
+                phi = (p.c - phi * phi) / p.n;
+                if (fabs(p.ec - fabs(phi)) > 1e-7) {  // pj_phi1_: Newton on the authalic q
+                    const double qs = phi, one_es = 1. - p.es;
+                    double Phi = asin(.5 * qs), dphi;
+                    int i = 15;
+                    do {
+                        const double sinpi = sin(Phi), cospi = cos(Phi), con = p.e * sinpi, com = 1. - con * con;
+                        dphi = .5 * com * com / cospi * (qs / one_es - sinpi / com + .5 / p.e * log((1. - con) / (1. + con)));
+                        Phi += dphi;
+                    } while (fabs(dphi) > 1e-10 && --i);
+                    phi = i ? Phi : NAN;
+                } else phi = phi < 0. ? -kHalfPi : kHalfPi;
+            } else {
+                phi = (p.c - phi * phi) / p.n2;
+                phi = fabs(phi) <= 1. ? asin(phi) : (phi < 0. ? -kHalfPi : kHalfPi);
+            }
+            lam = atan2(xs, ys) / p.n;
+        } else {
+            lam = 0.;
+            phi = p.n > 0. ? kHalfPi : -kHalfPi;
         }
     } else if (p.kind == kLaea) {  // PJ_laea.c e_inverse / s_inverse
         if (p.es != 0) {

@@ -13,7 +13,7 @@ Lambert conformal conic eq. 15-1..15-5; oblique transformation eq. 5-7..5-10b)
 with PROJ.4's conventions: longitude/latitude in radians at the pj_transform
 boundary, x = a*x' + x_0, lam = lon - lon_0 wrapped to [-pi, pi].
 Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered for
-merc, lcc, polar and oblique stere, laea, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
+merc, lcc, polar and oblique stere, laea, aea, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
 of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
 latitude pass unchanged between the two sides (no datum shift is restated; a pair
@@ -222,7 +222,7 @@ class _Proj:
     def _kind(self):
         if self.latlong:
             return "latlong"
-        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea"):
+        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea"):
             return self.name
         raise NotImplementedError("projection %s" % self.name)
 
@@ -698,6 +698,72 @@ class _Proj:
                 phi = phi - HALFPI
             lam = np.where((y == 0.) & (self.mode in ("E", "O")), 0., np.arctan2(x, y))
             return np.where(bad, np.nan, lam), np.where(bad, np.nan, phi)
+
+    # ---- Albers equal-area conic (Snyder eq. 14-1..14-21; the inverse on the ellipsoid iterates eq. 3-16)
+    def _setup_aea(self):
+        p = self.p
+        phi1 = _rad(p, "lat_1")
+        phi2 = _rad(p, "lat_2")  # PROJ.4 reads +lat_2 with default 0, not lat_1
+        if abs(phi1 + phi2) < _EPS10:
+            raise ValueError("aea: lat_1 = -lat_2")
+        self.n = sinphi = math.sin(phi1)
+        cosphi = math.cos(phi1)
+        secant = abs(phi1 - phi2) >= _EPS10
+        if self.es != 0.:
+            m1 = float(msfn(sinphi, cosphi, self.es))
+            ml1 = float(self._qsfn(sinphi))
+            if secant:
+                s2, c2 = math.sin(phi2), math.cos(phi2)
+                m2, ml2 = float(msfn(s2, c2, self.es)), float(self._qsfn(s2))
+                self.n = (m1 * m1 - m2 * m2) / (ml2 - ml1)
+            self.ec = 1. - .5 * (1. - self.es) * math.log((1. - self.e) / (1. + self.e)) / self.e
+            self.c = m1 * m1 + self.n * ml1
+            self.dd = 1. / self.n
+            self.rho0 = self.dd * math.sqrt(self.c - self.n * float(self._qsfn(math.sin(self.phi0))))
+        else:
+            if secant:
+                self.n = .5 * (self.n + math.sin(phi2))
+            self.n2 = self.n + self.n
+            self.c = cosphi * cosphi + self.n2 * sinphi
+            self.dd = 1. / self.n
+            self.rho0 = self.dd * math.sqrt(self.c - self.n2 * math.sin(self.phi0))
+
+    def _fwd_aea(self, lam, phi):
+        with np.errstate(invalid="ignore"):
+            rho = self.c - (self.n * self._qsfn(np.sin(phi)) if self.es != 0. else self.n2 * np.sin(phi))
+            bad = rho < 0.
+            rho = self.dd * np.sqrt(np.where(bad, 0., rho))
+            lam = lam * self.n
+            return np.where(bad, np.nan, rho * np.sin(lam)), np.where(bad, np.nan, self.rho0 - rho * np.cos(lam))
+
+    def _inv_aea(self, x, y):
+        y = self.rho0 - y
+        rho = np.hypot(x, y)
+        if self.n < 0.:
+            rho, x, y = -rho, -x, -y
+        with np.errstate(invalid="ignore", divide="ignore"):
+            q = rho / self.dd
+            if self.es != 0.:
+                q = (self.c - q * q) / self.n
+                phi = np.arcsin(np.clip(.5 * q, -1., 1.))   # pj_phi1_: Newton on the authalic q, at most 15 rounds, 1e-10
+                live = np.ones(np.shape(phi), dtype=bool)
+                for _ in range(15):
+                    sinpi, cospi = np.sin(phi), np.cos(phi)
+                    con = self.e * sinpi
+                    com = 1. - con * con
+                    dphi = .5 * com * com / cospi * (q / (1. - self.es) - sinpi / com + .5 / self.e * np.log((1. - con) / (1. + con)))
+                    phi = np.where(live, phi + dphi, phi)
+                    live = live & (np.abs(dphi) > 1e-10)
+                    if not live.any():
+                        break
+                phi = np.where(live, np.nan, phi)
+                phi = np.where(np.abs(self.ec - np.abs(q)) > 1e-7, phi, np.where(q < 0., -HALFPI, HALFPI))
+            else:
+                q = (self.c - q * q) / self.n2
+                phi = np.where(np.abs(q) <= 1., np.arcsin(np.clip(q, -1., 1.)), np.where(q < 0., -HALFPI, HALFPI))
+            lam = np.arctan2(x, y) / self.n
+            pole = rho == 0.
+            return np.where(pole, 0., lam), np.where(pole, HALFPI if self.n > 0. else -HALFPI, phi)
 
     # ---- general oblique transformation around a geographic "projection" (rotated pole)
     def _setup_ob_tran(self):

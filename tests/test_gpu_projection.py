@@ -27,7 +27,8 @@ MERC = "+proj=merc +lon_0=5 +lat_ts=30 +R=6371000"
 ROT = "+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06 +no_defs"
 LAEA_S = "+proj=laea +lat_0=52 +lon_0=10 +R=6371000"
 LAEA_SP = "+proj=laea +lat_0=90 +lon_0=-30 +R=6371000 +x_0=100"
-ALL = [GEO, STERE, STERE_OBL, STERE_EQ, STERE_S, LCC, LCC2, MERC, ROT, LAEA_S, LAEA_SP]
+AEA_S = "+proj=aea +lat_1=40 +lat_2=60 +lat_0=50 +lon_0=10 +R=6371000"
+ALL = [GEO, STERE, STERE_OBL, STERE_EQ, STERE_S, LCC, LCC2, MERC, ROT, LAEA_S, LAEA_SP, AEA_S]
 # on an ellipsoid (the UTM string is the one of test/testInterpolator.cc:422)
 GEO_W = "+proj=latlong +datum=WGS84"
 UTM33 = "+proj=utm +zone=33 +datum=WGS84 +no_defs"
@@ -45,7 +46,9 @@ MERC_W = "+proj=merc +lon_0=5 +lat_ts=30 +ellps=WGS84"
 LAEA_W = "+proj=laea +lat_0=52 +lon_0=10 +x_0=4321000 +y_0=3210000 +ellps=GRS80"   # ETRS89-LAEA
 LAEA_WP = "+proj=laea +lat_0=90 +lon_0=0 +ellps=WGS84"
 LAEA_WE = "+proj=laea +lat_0=0 +lon_0=20 +ellps=WGS84"
-ELLIPSOIDAL = [LAEA_W, LAEA_WP, LAEA_WE, UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
+AEA_W = "+proj=aea +lat_1=29.5 +lat_2=45.5 +lat_0=23 +lon_0=-96 +x_0=0 +y_0=0 +ellps=GRS80"
+AEA_W1 = "+proj=aea +lat_1=55 +lat_2=55 +lat_0=50 +lon_0=10 +ellps=WGS84"
+ELLIPSOIDAL = [AEA_W, AEA_W1, LAEA_W, LAEA_WP, LAEA_WE, UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
 
 
 @pytest.fixture(scope="module")

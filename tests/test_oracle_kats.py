@@ -300,7 +300,14 @@ SNYDER = [
     ("+proj=stere +ellps=intl +lat_0=-90 +lat_ts=-71 +lon_0=-100", (150., -75.), (-1540033.6, -560526.4)),
     ("+proj=stere +ellps=clrk66 +lat_0=40 +lon_0=-100 +k=0.9999", (-90., 30.), (971630.8, -1063049.3)),
     ("+proj=laea +ellps=clrk66 +lat_0=40 +lon_0=-100", (-110., 30.), (-965932.1, -1056814.9)),
+    ("+proj=aea +ellps=clrk66 +lat_1=29.5 +lat_2=45.5 +lat_0=23 +lon_0=-96", (-75., 35.), (1885472.7, 1535925.0)),
 ]
+
+
+def test_albers_on_the_unit_sphere():
+    """Snyder's spherical example: standard parallels 29.5 and 45.5, origin 23 N 96 W, the point 35 N 75 W."""
+    x, y = po.transform("+proj=latlong +R=1", "+proj=aea +R=1 +lat_1=29.5 +lat_2=45.5 +lat_0=23 +lon_0=-96", np.radians([-75.]), np.radians([35.]))
+    assert abs(x[0] - 0.2952720) < 1e-7 and abs(y[0] - 0.2416774) < 1e-7
 
 
 def test_lambert_azimuthal_equal_area_worked_examples():

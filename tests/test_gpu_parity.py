@@ -271,6 +271,33 @@ def test_fills_with_each_evaluation_of_the_sums(fa, monkeypatch, algo):
         assert cases.same(gotv[z], wantv)
 
 
+def test_fills_on_random_shapes(fa, monkeypatch):
+    """Forty slices of random size, hole pattern and parameters through both band geometries and all three fills:
+    every width class of the systolic kernels (narrower than a chunk, one band, ragged last band, several hand-off
+    windows) meets the CPU restatement."""
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        nx, ny = int(rng.integers(4, 900)), int(rng.integers(4, 400))
+        if case % 5 == 0:
+            nx, ny = ny, nx
+        f = cases.holes(1, ny, nx, seed=1000 + case, frac=float(rng.choice([0.02, 0.3, 0.8])), blobs=int(rng.integers(1, 9)))
+        if case == 7:
+            f[:] = np.nan          # nothing defined
+        if case == 8:
+            f = np.nan_to_num(f)   # nothing to fill
+        if case == 9:
+            f[0, :, 0] = np.nan; f[0, 0, :] = np.nan; f[0, -1, :] = np.nan; f[0, :, -1] = np.nan  # the whole border
+        relax, corr, loops = float(rng.choice([4.0, 0.3, 1e-9])), float(rng.choice([1.0, 1.6, 1.9])), int(rng.integers(1, 45))
+        repeat, weight = int(rng.integers(1, 25)), int(rng.integers(0, 4))
+        monkeypatch.setenv("FIMEX_AMD_FILL_GEOMETRY", "1" if case % 2 else "2")
+        got, nch = fa.fill2d_host(f, relax, corr, loops)
+        want, wn, rc = oracle.fill2d(f[0], relax, corr, loops)
+        assert rc == oracle.OK and nch[0] == wn and cases.same(got[0], want), (case, nx, ny, relax, corr, loops, cases.describe_mismatch(got[0], want))
+        gotc, nchc = fa.creepfill2d_host(f, repeat, weight)
+        wantc, wnc, rc = oracle.creepfill2d(f[0], repeat, weight)
+        assert rc == oracle.OK and nchc[0] == wnc and cases.same(gotc[0], wantc), (case, nx, ny, repeat, weight, cases.describe_mismatch(gotc[0], wantc))
+
+
 def test_fill2d_both_kernels_agree(fa, monkeypatch):
     """The systolic row-band kernel and the anti-diagonal wavefront kernel are two implementations of the same order."""
     f = cases.holes(2, 150, 210, seed=77)

@@ -271,6 +271,37 @@ def test_fills_with_each_evaluation_of_the_sums(fa, monkeypatch, algo):
         assert cases.same(gotv[z], wantv)
 
 
+def test_stored_type_regrid_on_random_shapes(fa):
+    """The LDS-staged kernels on 1- and 2-byte elements over random grid sizes (row lengths that are and are not multiples
+    of the 16-byte chunk of each element size), slice counts around the staging threshold, and an input that does not
+    start on a 4-byte boundary (gather form): all equal the oracle's three steps."""
+    import torch
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        dt = [np.int16, np.uint16, np.int8, np.uint8][case % 4]
+        method = [oracle.BILINEAR, oracle.NEAREST, oracle.BICUBIC][case % 3]
+        inX = int(rng.integers(3, 60)) * 4 if case % 6 else int(rng.integers(9, 200))
+        inY, outX, outY, nz = int(rng.integers(5, 140)), int(rng.integers(1, 260)), int(rng.integers(1, 180)), int(rng.integers(1, 12))
+        px, py = cases.backward_positions(inX, inY, outX, outY, seed=case)
+        info = np.iinfo(dt)
+        bad = float(info.max if case % 2 else info.min)
+        f = rng.integers(info.min, int(info.max) + 1, (nz, inY, inX)).astype(dt)
+        f.reshape(-1)[rng.random(f.size) < 0.04] = dt(bad)
+        code = oracle.cdm_type_of(dt)
+        want = oracle.interpolation_array2data(
+            oracle.interpolate_values(method, px, py, oracle.data2interpolation_array(f, bad), inX, inY, outX, outY), code, bad)
+        plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+        shift = 2 if case in (5, 11) else 0   # an odd element offset: the slices no longer start on 4-byte boundaries
+        raw = torch.zeros(f.nbytes + 8, dtype=torch.uint8, device="cuda")
+        raw[shift:shift + f.nbytes] = torch.from_numpy(f.view(np.uint8).ravel()).cuda()
+        out = torch.zeros(want.nbytes, dtype=torch.uint8, device="cuda")
+        fa.regrid_apply_typed_device(plan, raw.data_ptr() + shift, code, nz, bad, out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(dt).reshape(want.shape)
+        assert np.array_equal(got, want), (case, np.dtype(dt).name, method, inX, inY, outX, outY, nz, int((got != want).sum()))
+        plan.close()
+
+
 def test_fills_on_random_shapes(fa, monkeypatch):
     """Forty slices of random size, hole pattern and parameters through both band geometries and all three fills:
     every width class of the systolic kernels (narrower than a chunk, one band, ragged last band, several hand-off

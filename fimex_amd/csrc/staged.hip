@@ -260,6 +260,22 @@ __device__ __forceinline__ float lds_value(const char* buf, uint32_t floatByteOf
     else return as_float_nan(*reinterpret_cast<const T*>(buf + floatByteOff / 4 * sizeof(T)), bad, hasBad);
 }
 
+// two neighbouring 1- or 2-byte elements: the two dwords that hold them in one ds_read2_b32, shifted into place
+template <typename T>
+__device__ __forceinline__ void lds_pair(const char* buf, uint32_t floatByteOff, float bad, bool hasBad, float& first, float& second)
+{
+    const uint32_t byteOff = floatByteOff / 4 * sizeof(T);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(buf + (byteOff & ~3u));
+    const uint32_t both = __builtin_amdgcn_alignbit(w[1], w[0], (byteOff & 3u) * 8u);
+    if constexpr (sizeof(T) == 2) {
+        first = as_float_nan((T)(unsigned short)(both & 0xffffu), bad, hasBad);
+        second = as_float_nan((T)(unsigned short)(both >> 16), bad, hasBad);
+    } else {
+        first = as_float_nan((T)(unsigned char)(both & 0xffu), bad, hasBad);
+        second = as_float_nan((T)(unsigned char)((both >> 8) & 0xffu), bad, hasBad);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void store_result(rsrc_t ro, uint32_t cellByteOff, float r, T fill)
 {
@@ -458,9 +474,12 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
                     const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
                     const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
                     s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
-                } else {
+                } else if constexpr (EB == 4) {
                     s00[k] = lds_value<T>(curb, row[k][0], a.bad, hasBad); s01[k] = lds_value<T>(curb, row[k][0] + 4, a.bad, hasBad);
                     s10[k] = lds_value<T>(curb, row[k][1], a.bad, hasBad); s11[k] = lds_value<T>(curb, row[k][1] + 4, a.bad, hasBad);
+                } else {
+                    lds_pair<T>(curb, row[k][0], a.bad, hasBad, s00[k], s01[k]);
+                    lds_pair<T>(curb, row[k][1], a.bad, hasBad, s10[k], s11[k]);
                 }
             }
 #pragma unroll

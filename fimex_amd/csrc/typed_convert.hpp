@@ -34,6 +34,13 @@ template <typename T>
 __device__ __forceinline__ T from_float_fill(float v, T fill)
 {
     if (isnan(v)) return fill;
+    if (std::is_integral<T>::value && fabsf(v) < 2147483648.f) {
+        // lround of a float inside the int range, without the detour through double: the fraction v - trunc(v) is exact
+        // in float, and from 2^23 on v is an integer already; then int -> T as the reference's static_cast
+        const float t = truncf(v);
+        const float r = t + ((fabsf(v - t) >= 0.5f) ? copysignf(1.f, v) : 0.f);
+        return (T)(int)r;
+    }
     const double d = 1.0 * (double)v + 0.0;  // turns -0.0 into +0.0, as the reference does
     if (std::is_integral<T>::value) return (T)mifi_round(d);
     return (T)d;

@@ -101,8 +101,14 @@ def cpu_baseline(wl, px, py, base, budget_s):
     oracle.interpolate_values(oracle.BILINEAR, px, py, f[:1], wl.inX, wl.inY, wl.outX, wl.outY, nthreads=1)
     single = time.perf_counter() - t1
     med = float(np.median(times))
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {
-        "value": cells / med / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+        "value": cells / med / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port", "cpu_model": model, "host_cpus": avail,
         "sample": "%d calls of one time step x %d levels (%.0f Mcells each) of the same 4000x3000->2000x2000 bilinear "
                   "plan, OpenMP over output cells on %d threads, median; 1 thread: %.1f Mcells/s"
                   % (len(times), levels, cells / 1e6, cores, wl.outX * wl.outY / single / 1e6),

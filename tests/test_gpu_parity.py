@@ -644,6 +644,17 @@ def test_log_blends_reject_non_positive_coordinates_and_kats(fa):
         assert abs(fa.get_values_1d_host(fa.BLEND_LOG_LOG, A, B, 1000., 100., x)[0] - w) / w < 1e-5
 
 
+def test_reference_kats_of_the_linear_family_on_the_gpu(fa):
+    """test/testInterpolation.cc:685-731: in0 = 200 at a = 2, in1 = 300 at b = 3, x = 0.5 .. 4.5."""
+    A, B = np.array([200], np.float32), np.array([300], np.float32)
+    want = {fa.BLEND_LINEAR_NO_EXTRAPOL: (np.nan, np.nan, 250, np.nan, np.nan), fa.BLEND_LINEAR_CONST_EXTRAPOL: (200, 200, 250, 300, 300),
+            fa.BLEND_LINEAR_WEAK_EXTRAPOL: (np.nan, 150, 250, 350, np.nan), fa.BLEND_LINEAR: (50, 150, 250, 350, 450)}
+    for kind, expect in want.items():
+        for x, w in zip((0.5, 1.5, 2.5, 3.5, 4.5), expect):
+            out = fa.get_values_1d_host(kind, A, B, 2., 3., x)
+            assert (np.isnan(out[0]) and np.isnan(w)) or abs(out[0] - w) < 0.01, (kind, x, out, w)
+
+
 def test_blend_device_in_place_and_double(fa):
     import torch
     rng = np.random.default_rng(2)

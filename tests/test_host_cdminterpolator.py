@@ -379,3 +379,85 @@ def test_get_data_slice_with_a_slicebuilder(tmp_path, coordtest):
     wind = np.fromfile(out / "x_wind_10m_2.f32", dtype=np.float32).reshape(-1, 200, 200)
     row = np.fromfile(out / "x_wind_10m_2_slice.f32", dtype=np.float32).reshape(1, 1, 200)
     assert cases.same(row, wind[:1, 199:, :])
+
+
+# ---------------------------------------------------------------- the reference's own file-based tests on the ERA-Interim fixture
+@pytest.fixture(scope="module")
+def erai(golden_dir):
+    """test/erai.sfc.40N.0.75d.200301011200.nc (NetCDF-3 classic): skin temperature as double on a 6 x 11 lat/lon grid with
+    descending latitudes, 8 time steps; test/template_noaa17.nc: 2-D longitude / latitude of a 29 x 31 satellite swath."""
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "erai.sfc.40N.0.75d.200301011200.nc"), "r", mmap=False) as f:
+        v = f.variables
+        d = dict(lon=v["longitude"].data.astype(np.float64), lat=v["latitude"].data.astype(np.float64),
+                 proj=v["projection_regular_ll"].proj4.decode(), skt=v["ga_skt"].data.astype(np.float64).reshape(8, 1, 11, 6))
+    with netcdf_file(os.path.join(golden_dir, "template_noaa17.nc"), "r", mmap=False) as f:
+        d["tlon"] = f.variables["longitude"].data.astype(np.float32)
+        d["tlat"] = f.variables["latitude"].data.astype(np.float32)
+    return d
+
+
+def _erai_spec(tmp, e, method, extra):
+    e["lon"].tofile(tmp / "x.f64"); e["lat"].tofile(tmp / "y.f64"); e["skt"].tofile(tmp / "skt.f64")
+    return ["proj " + e["proj"], "xaxis %s" % (tmp / "x.f64"), "yaxis %s" % (tmp / "y.f64"), "method " + method,
+            "var ga_skt 1 %s nan type double" % (tmp / "skt.f64")] + list(extra)
+
+
+def _erai_oracle(e, code, px, py, step, n_out_x, n_out_y):
+    src = oracle.data2interpolation_array(e["skt"][step], 9.9692099683868690e+36)   # CDM::getFillValue default of a double variable
+    return oracle.interpolate_values(code, px, py, src, 6, 11, n_out_x, n_out_y).astype(np.float64)
+
+
+def test_erai_to_the_noaa17_template(tmp_path, erai):
+    """test/testInterpolator.cc:220-239 (test_interpolator_template): bicubic onto the template's 29 x 31 swath; the first
+    seven values of ga_skt are defined and lie between 270 and 280 K."""
+    e = erai
+    e["tlon"].tofile(tmp_path / "tlon.f32"); e["tlat"].tofile(tmp_path / "tlat.f32")
+    gets = ["get ga_skt %d" % t for t in range(8)]
+    out, stdout = _run(tmp_path, _erai_spec(tmp_path, e, "bicubic", ["template %s %s 29 31" % (tmp_path / "tlon.f32", tmp_path / "tlat.f32")] + gets))
+    assert "outX 29 outY 31" in stdout
+    first = np.fromfile(out / "ga_skt_0.raw", dtype=np.float64)
+    assert first.size == 29 * 31                                               # :228-231
+    assert np.all(np.isfinite(first[:7]) & (first[:7] > 270) & (first[:7] < 280)), first[:8]   # :235-237
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    for t in range(8):
+        got = np.fromfile(out / ("ga_skt_%d.raw" % t), dtype=np.float64)
+        want = _erai_oracle(e, oracle.BICUBIC, px, py, t, 29, 31).ravel()
+        want = np.where(np.isnan(want), 9.9692099683868690e+36, want)          # interpolationArray2Data: the double variable's fill value
+        assert np.array_equal(got, want), (t, np.abs(got - want).max())
+
+
+def test_erai_to_ten_points(tmp_path, erai):
+    """test/testInterpolator.cc:241-264 (test_interpolator_latlon): bilinear to ten stations; all values defined, the
+    first between 270 and 280 K, all between 266 and 281.1 K, over the eight time steps."""
+    e = erai
+    lat = np.array([59.109, 59.052, 58.994, 58.934, 58.874, 58.812, 58.749, 58.685, 58.62, 64.])
+    lon = np.array([4.965, 5.13, 5.296, 5.465, 5.637, 5.81, 5.986, 6.164001, 6.344, 3.])
+    lon.tofile(tmp_path / "plon.f64"); lat.tofile(tmp_path / "plat.f64")
+    gets = ["get ga_skt %d" % t for t in range(8)]
+    out, stdout = _run(tmp_path, _erai_spec(tmp_path, e, "bilinear", ["points %s %s" % (tmp_path / "plon.f64", tmp_path / "plat.f64")] + gets))
+    assert "outX 10 outY 1" in stdout
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    allv = np.stack([np.fromfile(out / ("ga_skt_%d.raw" % t), dtype=np.float64) for t in range(8)])
+    assert allv.shape == (8, 10)
+    assert 270 < allv[0, 0] < 280                                             # :258
+    assert np.all(np.isfinite(allv) & (allv > 266) & (allv < 281.1)), allv     # :259-261
+    for t in range(8):
+        assert np.array_equal(allv[t], _erai_oracle(e, oracle.BILINEAR, px, py, t, 10, 1).ravel())
+
+
+def test_erai_cross_sections(tmp_path, erai):
+    """test/testInterpolator.cc:474-497 (test_interpolator_vcross): Oslo - Trondheim - Tromso and Bergen - Oslo on the
+    0.75 degree grid: two named sections, more than five points."""
+    out, stdout = _run(tmp_path, _erai_spec(tmp_path, erai, "bilinear", [
+        "crosssection OsloTrondheimTromso 10.74 59.9 10.3951 63.4305 18.9551 69.6489", "crosssection BergenOslo 5.3290 60.3983 10.74 59.9",
+        "get ga_skt 0"]))
+    assert "vcross OsloTrondheimTromso BergenOslo" in stdout
+    bnds = np.fromfile(out / "vcross_bnds.i32", dtype=np.int32).reshape(-1, 2)
+    lon = np.fromfile(out / "target_lon.f64")
+    assert bnds.shape == (2, 2) and lon.size > 5 and bnds[0, 0] == 0 and bnds[1, 1] == lon.size - 1 and bnds[1, 0] == bnds[0, 1] + 1
+    assert abs(lon[0] - 10.74) < 1e-9 and abs(lon[-1] - 10.74) < 1e-9 and abs(lon[bnds[1, 0]] - 5.3290) < 1e-9
+    got = np.fromfile(out / "ga_skt_0.raw", dtype=np.float64)
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    want = _erai_oracle(erai, oracle.BILINEAR, px, py, 0, lon.size, 1).ravel()
+    assert np.array_equal(got, np.where(np.isnan(want), 9.9692099683868690e+36, want))

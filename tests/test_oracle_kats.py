@@ -290,6 +290,53 @@ def test_extrapolation_variants_of_the_linear_blend():
     assert cases.same(oracle.get_values_1d(oracle.BLEND_NEAREST, A, B, 0., 1., .9)[0], A)
 
 
+def test_reference_kats_of_the_linear_family():
+    """test/testInterpolation.cc:685-731 literally: in0 = 200 at a = 2, in1 = 300 at b = 3, x = 0.5 .. 4.5."""
+    A, B = np.array([200], np.float32), np.array([300], np.float32)
+    xs = (0.5, 1.5, 2.5, 3.5, 4.5)
+    want = {oracle.BLEND_LINEAR_NO_EXTRAPOL: (np.nan, np.nan, 250, np.nan, np.nan),      # :690-694
+            oracle.BLEND_LINEAR_CONST_EXTRAPOL: (200, 200, 250, 300, 300),               # :702-706
+            oracle.BLEND_LINEAR_WEAK_EXTRAPOL: (np.nan, 150, 250, 350, np.nan),          # :714-718
+            oracle.BLEND_LINEAR: (50, 150, 250, 350, 450)}                               # :726-730
+    for kind, expect in want.items():
+        for x, w in zip(xs, expect):
+            out, rc = oracle.get_values_1d(kind, A, B, 2., 3., x)
+            assert rc == oracle.OK
+            assert (np.isnan(out[0]) and np.isnan(w)) or abs(out[0] - w) < 0.01, (kind, x, out, w)
+
+
+def _erai(golden_dir):
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "erai.sfc.40N.0.75d.200301011200.nc"), "r", mmap=False) as f:
+        v = f.variables
+        e = dict(lon=v["longitude"].data.astype(np.float64), lat=v["latitude"].data.astype(np.float64),
+                 proj=v["projection_regular_ll"].proj4.decode(), skt=v["ga_skt"].data.astype(np.float32).reshape(8, 11, 6))
+    with netcdf_file(os.path.join(golden_dir, "template_noaa17.nc"), "r", mmap=False) as f:
+        e["tlon"], e["tlat"] = f.variables["longitude"].data.astype(np.float64), f.variables["latitude"].data.astype(np.float64)
+    return e
+
+
+def _erai_positions(e, lon_deg, lat_deg):
+    """src/CDMInterpolator.cc:1761-1793: template degrees -> radians -> the file's projection -> positions on its axes."""
+    x, y = po.transform("+proj=latlong +datum=WGS84 +towgs84=0,0,0 +no_defs", e["proj"], np.radians(lon_deg), np.radians(lat_deg))
+    return (oracle.points2position(x, np.radians(e["lon"]), oracle.LONGITUDE), oracle.points2position(y, np.radians(e["lat"]), oracle.LATITUDE))
+
+
+def test_reference_file_tests_on_the_erai_fixture(golden_dir):
+    """test/testInterpolator.cc:220-264 with the oracle alone: ERA-Interim skin temperature (test/erai.sfc.40N...nc) bicubic
+    onto the NOAA-17 swath of test/template_noaa17.nc -- the first seven values defined, 270..280 K -- and bilinear to ten
+    stations -- all defined, 266..281.1 K, the first 270..280 K."""
+    e = _erai(golden_dir)
+    px, py = _erai_positions(e, e["tlon"].ravel(), e["tlat"].ravel())
+    out = oracle.interpolate_values(oracle.BICUBIC, px, py, e["skt"][0:1], 6, 11, 29, 31).ravel()
+    assert out.size == 29 * 31 and np.all(np.isfinite(out[:7]) & (out[:7] > 270) & (out[:7] < 280)), out[:8]
+    lat = np.array([59.109, 59.052, 58.994, 58.934, 58.874, 58.812, 58.749, 58.685, 58.62, 64.])
+    lon = np.array([4.965, 5.13, 5.296, 5.465, 5.637, 5.81, 5.986, 6.164001, 6.344, 3.])
+    px, py = _erai_positions(e, lon.astype(np.float32).astype(np.float64), lat.astype(np.float32).astype(np.float64))
+    pts = oracle.interpolate_values(oracle.BILINEAR, px, py, e["skt"], 6, 11, 10, 1).reshape(8, 10)
+    assert 270 < pts[0, 0] < 280 and np.all(np.isfinite(pts) & (pts > 266) & (pts < 281.1)), pts
+
+
 # ---------------------------------------------------------------- ellipsoidal projections (SURVEY 8f n2, testInterpolator.cc:422)
 # Worked numerical examples of Snyder, "Map Projections - A Working Manual" (USGS PP 1395), appendix A: the published
 # known answers the PROJ.4 series are checked against in the absence of the library (values in metres, one decimal).

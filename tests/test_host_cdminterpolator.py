@@ -461,3 +461,40 @@ def test_erai_cross_sections(tmp_path, erai):
     px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
     want = _erai_oracle(erai, oracle.BILINEAR, px, py, 0, lon.size, 1).ravel()
     assert np.array_equal(got, np.where(np.isnan(want), 9.9692099683868690e+36, want))
+
+
+def test_two_coordinate_systems_fixture(tmp_path, golden_dir):
+    """test/testInterpolator.cc:123-181 (test_interpolator2coords): temp2 of test/twoCoordsTest.nc lives on the file's second
+    grid (x_c, y_c, longitude2 / latitude2, packed shorts); coord_kdtree and nearestneighbor onto a 12 x 12 polar-stereographic
+    grid at 50 km leave more than 100 cells above 29000 in the first time step."""
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(golden_dir, "twoCoordsTest.nc"), "r", mmap=False) as f:
+        v = f.variables
+        xc, yc = v["x_c"].data.astype(np.float64), v["y_c"].data.astype(np.float64)
+        lon2, lat2 = v["longitude2"].data.astype(np.float64), v["latitude2"].data.astype(np.float64)
+        temp2 = v["temp2"].data.astype(np.int16)
+        proj = v["projection_1"].proj4.decode()
+    xc.tofile(tmp_path / "x.f64"); yc.tofile(tmp_path / "y.f64"); lon2.tofile(tmp_path / "lon.f64"); lat2.tofile(tmp_path / "lat.f64")
+    temp2.tofile(tmp_path / "temp2.i16")
+    ox = -1705516 + 50000. * np.arange(12)
+    oy = -6872225 + 50000. * np.arange(12)
+    ox.tofile(tmp_path / "ox.f64"); oy.tofile(tmp_path / "oy.f64")
+    target = "+proj=stere +lat_0=90 +lon_0=0 +lat_ts=60 +ellps=sphere +a=6371000 +e=0"
+    results = {}
+    for method in ("coord_kdtree", "nearestneighbor"):
+        lines = ["proj " + proj, "xaxis %s" % (tmp_path / "x.f64"), "yaxis %s" % (tmp_path / "y.f64"),
+                 "lon2d %s" % (tmp_path / "lon.f64"), "lat2d %s" % (tmp_path / "lat.f64"), "method " + method, "outproj " + target,
+                 "outx %s m" % (tmp_path / "ox.f64"), "outy %s m" % (tmp_path / "oy.f64"),
+                 "var temp2 1 %s nan type short" % (tmp_path / "temp2.i16"), "get temp2 0"]
+        out, _ = _run(tmp_path, lines)
+        got = np.fromfile(out / "temp2_0.raw", dtype=np.int16)
+        assert got.size == 144
+        assert (got > 29000).sum() > 100, (method, (got > 29000).sum())       # :151, :176
+        results[method] = got
+        # the regrid itself: nearest cell of the plan the host built, on the raw shorts
+        px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+        src = oracle.data2interpolation_array(temp2[0], -32767.0)               # CDM::getFillValue default of a short
+        want = oracle.interpolation_array2data(oracle.interpolate_values(oracle.NEAREST, px, py, src, 11, 10, 12, 12), oracle.CDM_SHORT, -32767.0)
+        assert np.array_equal(got, want.ravel())
+    inside = (results["coord_kdtree"] != -32767) & (results["nearestneighbor"] != -32767)
+    assert inside.sum() > 100 and np.array_equal(results["coord_kdtree"][inside], results["nearestneighbor"][inside])

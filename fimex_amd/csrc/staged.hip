@@ -329,12 +329,18 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     constexpr uint32_t EB = sizeof(T);
     // DMA pieces per lane and slice: 16-byte chunks for 4-byte elements, 4-byte pieces otherwise (a chunk of the plan is
     // 4 elements = 4 * EB bytes = EB pieces)
-    constexpr int UN = (EB == 4) ? KMAX : KMAX * (int)EB;
+    // 2-byte elements: 16-byte pieces of 8 elements = two chunks; every row segment is padded to an even number of chunks in
+    // the LDS image (kWide), so that a piece never spans two segments -- a quarter of the DMA instructions of 4-byte pieces,
+    // which matter more than the bytes (each vector-memory wave instruction costs the address unit ~16 clocks).
+    // 1-byte elements: 4-byte pieces (a chunk is one piece).
+    constexpr bool kWide = (EB == 2);
+    constexpr int UN = (EB == 4) ? KMAX : (kWide ? KMAX / 2 + 1 : KMAX);
     const bool hasBad = a.hasBad != 0;
     const T fillT = kFloat ? T() : static_cast<T>(a.fillOut);  // ScaleValue's newFill_ (Utils.h:456)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // NBUF buffers of KMAX*256*4 floats (+ slack), then the row table
     constexpr uint32_t kBufFloats = KMAX * kBlock * 4 + 4;
     uint32_t* shRows = reinterpret_cast<uint32_t*>(smem + NBUF * kBufFloats);  // [2 * nr]
+    uint32_t* shPiece = shRows + 2 * kMaxRows;                                   // kWide: first piece of every segment, [nr + 1]
 
     // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an L2):
     //   xcdRemap 0: tiles in dispatch order (neighbours on different XCDs) -- the default, measured as good as any;
@@ -406,21 +412,57 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     const uint32_t* rows = a.tileRows + (size_t)tile * 2 * kMaxRows;
     for (uint32_t i = threadIdx.x; i < 2 * nr; i += kBlock) shRows[i] = rows[i];
     __syncthreads();
-    // piece u = threadIdx.x + j*256: 16-byte chunk u (4-byte elements), or 4-byte piece u % EB of chunk u / EB
+    auto segment_of_chunk = [&](uint32_t c) {  // last segment whose first chunk <= c
+        uint32_t lo = 0, hi = nr - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (shRows[2 * mid + 1] <= c) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    if constexpr (kWide) {
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (uint32_t r = 0; r < nr; ++r) {
+                shPiece[r] = acc;
+                const uint32_t nch = (r + 1 < nr ? shRows[2 * (r + 1) + 1] : totalChunks) - shRows[2 * r + 1];
+                acc += (nch + 1) / 2;
+            }
+            shPiece[nr] = acc;
+        }
+        __syncthreads();
+        // the plan's LDS offsets count elements of an image without padding: move them to the padded one
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+#pragma unroll
+            for (int i = 0; i < STENCIL; ++i) {
+                if (undef[k]) continue;
+                const uint32_t o = row[k][i] / 4u;                     // element offset in the unpadded image
+                const uint32_t r = segment_of_chunk(o / 4u);
+                row[k][i] = (shPiece[r] * 8u + (o - shRows[2 * r + 1] * 4u)) * 4u;
+            }
+        }
+    }
+    // piece u = threadIdx.x + j*256: 16-byte chunk u (4-byte elements), 16-byte piece u of the padded image (2-byte
+    // elements), or 4-byte chunk u (1-byte elements)
     uint32_t gOff[UN];  // byte offset of the piece inside a source slice, ~0u = none (dropped by the bounds check: zeros)
 #pragma unroll
     for (int j = 0; j < UN; ++j) {
         const uint32_t u = threadIdx.x + j * kBlock;
-        const uint32_t c = (EB == 4) ? u : u / EB;
         gOff[j] = 0xFFFFFFFFu;
-        if (c < totalChunks) {
-            uint32_t lo = 0, hi = nr - 1;  // last row whose first chunk <= c
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (shRows[2 * mid + 1] <= c) lo = mid; else hi = mid - 1;
+        if constexpr (kWide) {
+            if (u < shPiece[nr]) {
+                uint32_t lo = 0, hi = nr - 1;  // last segment whose first piece <= u
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (shPiece[mid] <= u) lo = mid; else hi = mid - 1;
+                }
+                // (the last piece of a segment with an odd number of chunks reads four elements past it: never used)
+                gOff[j] = (shRows[2 * lo] + (u - shPiece[lo]) * 8u) * EB;
             }
-            const uint32_t elem = shRows[2 * lo] + (c - shRows[2 * lo + 1]) * 4u;  // first element of the chunk
-            gOff[j] = (EB == 4) ? elem * 4u : elem * EB + (u % EB) * 4u;
+        } else if (u < totalChunks) {
+            const uint32_t lo = segment_of_chunk(u);
+            gOff[j] = (shRows[2 * lo] + (u - shRows[2 * lo + 1]) * 4u) * EB;  // first element of the chunk
         }
     }
 
@@ -431,7 +473,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
         const rsrc_t rs = make_rsrc(inBase + (size_t)z * inBytes, (a.ablate & 1) ? 0u : inBytes);
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
-            if constexpr (EB == 4) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
+            if constexpr (EB == 4 || kWide) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
             else dma4(rs, dst + (waveChunk + j * kBlock), gOff[j]);
         }
     };
@@ -540,7 +582,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
 template <int STENCIL, int PER, int KMAX, int NBUF, typename T>
 void launch_staged_n(const StagedArgs& a, dim3 grid, hipStream_t stream)
 {
-    constexpr size_t ldsBytes = (size_t)NBUF * (KMAX * kBlock * 4 + 4) * sizeof(float) + 2 * kMaxRows * sizeof(uint32_t);
+    constexpr size_t ldsBytes = (size_t)NBUF * (KMAX * kBlock * 4 + 4) * sizeof(float) + (3 * kMaxRows + 1) * sizeof(uint32_t);
     static_assert(ldsBytes <= 160 * 1024, "slice ring does not fit the CU's LDS");
     allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply<STENCIL, PER, KMAX, NBUF, T>), ldsBytes);
     staged_apply<STENCIL, PER, KMAX, NBUF, T><<<grid, kBlock, ldsBytes, stream>>>(a);

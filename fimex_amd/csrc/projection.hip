@@ -5,7 +5,7 @@
 // PROJ.4 is a third-party library that is not part of the reference tree; the projections are implemented from their
 // published closed forms on the sphere (Snyder, "Map Projections - A Working Manual", USGS PP 1395) with PROJ.4's
 // conventions at the pj_transform boundary: geographic coordinates in radians, projected x = a * x' + x_0, longitudes
-// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, ob_tran +
+// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, ob_tran +
 // o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
 // an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
@@ -30,7 +30,7 @@ constexpr double kSpi = 3.14159265359;  // PROJ.4's adjlon threshold
 constexpr double kEps10 = 1e-10;
 constexpr double kDegToRad = .0174532925199432958;  // proj_api.h DEG_TO_RAD
 
-enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea };
+enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea, kGeos };
 enum StereMode { kNorth = 0, kSouth, kOblique, kEquatorial };
 
 struct ProjParams {
@@ -43,6 +43,7 @@ struct ProjParams {
     double Qn, Zb, cgb[6], cbg[6], utg[6], gtu[6];  // etmerc
     double qp, rq, dd, xmf, ymf, sinb1, cosb1, apa[3];  // laea (aea: dd, and n, c, rho0 of lcc)
     double ec, n2;                // aea
+    double radius_g, radius_g_1, radius_p, radius_p2, radius_p_inv2, C;  // geos (flip_axis in mode)
     double towgs84[7];            // only compared between the two sides
 };
 
@@ -379,6 +380,26 @@ ProjParams parse_proj4(const char* text)
             p.esp = p.k0;
             p.ml0 = .5 * p.esp;
         }
+    } else if (name == "geos") {  // PJ_geos.c setup
+        p.kind = kGeos;
+        const double h = num("h", 0);
+        if (!(h > 0)) throw Error("geos needs +h > 0: " + proj4);
+        if (p.phi0 != 0) throw Error("geos: lat_0 must be 0: " + proj4);
+        p.mode = 0;
+        if (has("sweep")) {
+            if (par["sweep"] != "x" && par["sweep"] != "y") throw Error("geos: +sweep must be x or y: " + proj4);
+            p.mode = par["sweep"] == "x";
+        }
+        p.radius_g_1 = h / p.a;
+        p.radius_g = 1. + p.radius_g_1;
+        p.C = p.radius_g * p.radius_g - 1.0;
+        if (p.es != 0) {
+            p.radius_p = std::sqrt(1. - p.es);
+            p.radius_p2 = 1. - p.es;
+            p.radius_p_inv2 = 1. / (1. - p.es);
+        } else {
+            p.radius_p = p.radius_p2 = p.radius_p_inv2 = 1.;
+        }
     } else if (name == "aea") {  // PJ_aea.c setup
         p.kind = kAea;
         const double phi1 = rad("lat_1", 0), phi2 = rad("lat_2", 0);
@@ -543,6 +564,16 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
                 if (phi < 0.) py = -py;
                 py = p.esp * (py - p.phi0);
             }
+        }
+    } else if (p.kind == kGeos) {  // PJ_geos.c e_forward (the spherical form is this one with radius_p = 1)
+        phi = atan(p.radius_p2 * tan(phi));
+        const double r = p.radius_p / hypot(p.radius_p * cos(phi), sin(phi));
+        const double Vx = r * cos(lam) * cos(phi), Vy = r * sin(lam) * cos(phi), Vz = r * sin(phi);
+        if (((p.radius_g - Vx) * Vx - Vy * Vy - Vz * Vz * p.radius_p_inv2) < 0.) { px = NAN; py = NAN; }  // behind the limb
+        else {
+            const double tmp = p.radius_g - Vx;
+            if (p.mode) { px = p.radius_g_1 * atan(Vy / hypot(Vz, tmp)); py = p.radius_g_1 * atan(Vz / tmp); }
+            else { px = p.radius_g_1 * atan(Vy / tmp); py = p.radius_g_1 * atan(Vz / hypot(Vy, tmp)); }
         }
     } else if (p.kind == kAea) {  // PJ_aea.c e_forward
         double rho = p.c - (p.es != 0 ? p.n * qsfn(sin(phi), p.e, 1. - p.es) : p.n2 * sin(phi));
@@ -740,6 +771,24 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
             phi = asin(sqrt((1. - h * h) / (1. + g * g)));
             if (ys < 0. && -phi + p.phi0 < 0.) phi = -phi;  // the hemisphere test of PROJ 4.9 (4.8 and older: y < 0 alone, wrong for lat_0 != 0)
             lam = (g != 0. || h != 0.) ? atan2(g, h) : 0.;
+        }
+    } else if (p.kind == kGeos) {  // PJ_geos.c e_inverse
+        double Vx = -1.0, Vy, Vz;
+        if (p.mode) { Vz = tan(ys / p.radius_g_1); Vy = tan(xs / p.radius_g_1) * hypot(1.0, Vz); }
+        else { Vy = tan(xs / p.radius_g_1); Vz = tan(ys / p.radius_g_1) * hypot(1.0, Vy); }
+        double a = Vz / p.radius_p;
+        a = Vy * Vy + a * a + Vx * Vx;
+        const double b = 2 * p.radius_g * Vx;
+        const double det = (b * b) - 4 * a * p.C;
+        if (det < 0.) { lam = NAN; phi = NAN; }  // off the disc
+        else {
+            const double k = (-b - sqrt(det)) / (2. * a);
+            Vx = p.radius_g + k * Vx;
+            Vy *= k;
+            Vz *= k;
+            lam = atan2(Vy, Vx);
+            phi = atan(Vz * cos(lam) / Vx);
+            phi = atan(p.radius_p_inv2 * tan(phi));
         }
     } else if (p.kind == kAea) {  // PJ_aea.c e_inverse
         ys = p.rho0 - ys;

@@ -13,7 +13,7 @@ Lambert conformal conic eq. 15-1..15-5; oblique transformation eq. 5-7..5-10b)
 with PROJ.4's conventions: longitude/latitude in radians at the pj_transform
 boundary, x = a*x' + x_0, lam = lon - lon_0 wrapped to [-pi, pi].
 Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered for
-merc, lcc, polar and oblique stere, laea, aea, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
+merc, lcc, polar and oblique stere, laea, aea, geos, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
 of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
 latitude pass unchanged between the two sides (no datum shift is restated; a pair
@@ -222,7 +222,7 @@ class _Proj:
     def _kind(self):
         if self.latlong:
             return "latlong"
-        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea"):
+        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea", "geos"):
             return self.name
         raise NotImplementedError("projection %s" % self.name)
 
@@ -764,6 +764,60 @@ class _Proj:
             lam = np.arctan2(x, y) / self.n
             pole = rho == 0.
             return np.where(pole, 0., lam), np.where(pole, HALFPI if self.n > 0. else -HALFPI, phi)
+
+    # ---- geostationary satellite view (PJ_geos.c; CGMS 03 "LRIT/HRIT global specification" 4.4.3.2)
+    def _setup_geos(self):
+        p = self.p
+        self.h = float(p.get("h", 0.))
+        if self.h <= 0.:
+            raise ValueError("geos needs +h > 0 (PROJ.4 error -30)")
+        if self.phi0 != 0.:
+            raise ValueError("geos: lat_0 must be 0 (PROJ.4 error -46)")
+        sweep = p.get("sweep")
+        if sweep not in (None, "x", "y"):
+            raise ValueError("geos: +sweep must be x or y")
+        self.flip_axis = sweep == "x"
+        self.radius_g_1 = self.h / self.a
+        self.radius_g = 1. + self.radius_g_1
+        self.C = self.radius_g * self.radius_g - 1.
+        if self.es != 0.:
+            self.radius_p, self.radius_p2, self.radius_p_inv2 = math.sqrt(1. - self.es), 1. - self.es, 1. / (1. - self.es)
+        else:
+            self.radius_p = self.radius_p2 = self.radius_p_inv2 = 1.
+
+    def _fwd_geos(self, lam, phi):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            phi = np.arctan(self.radius_p2 * np.tan(phi))
+            r = self.radius_p / np.hypot(self.radius_p * np.cos(phi), np.sin(phi))
+            vx, vy, vz = r * np.cos(lam) * np.cos(phi), r * np.sin(lam) * np.cos(phi), r * np.sin(phi)
+            hidden = ((self.radius_g - vx) * vx - vy * vy - vz * vz * self.radius_p_inv2) < 0.
+            tmp = self.radius_g - vx
+            if self.flip_axis:
+                x, y = self.radius_g_1 * np.arctan(vy / np.hypot(vz, tmp)), self.radius_g_1 * np.arctan(vz / tmp)
+            else:
+                x, y = self.radius_g_1 * np.arctan(vy / tmp), self.radius_g_1 * np.arctan(vz / np.hypot(vy, tmp))
+            return np.where(hidden, np.nan, x), np.where(hidden, np.nan, y)
+
+    def _inv_geos(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            vx = -1.
+            if self.flip_axis:
+                vz = np.tan(y / self.radius_g_1)
+                vy = np.tan(x / self.radius_g_1) * np.hypot(1., vz)
+            else:
+                vy = np.tan(x / self.radius_g_1)
+                vz = np.tan(y / self.radius_g_1) * np.hypot(1., vy)
+            a = vz / self.radius_p
+            a = vy * vy + a * a + vx * vx
+            b = 2. * self.radius_g * vx
+            det = b * b - 4. * a * self.C
+            k = (-b - np.sqrt(det)) / (2. * a)
+            vx = self.radius_g + k * vx
+            vy, vz = vy * k, vz * k
+            lam = np.arctan2(vy, vx)
+            phi = np.arctan(vz * np.cos(lam) / vx)
+            phi = np.arctan(self.radius_p_inv2 * np.tan(phi))
+            return np.where(det < 0., np.nan, lam), np.where(det < 0., np.nan, phi)
 
     # ---- general oblique transformation around a geographic "projection" (rotated pole)
     def _setup_ob_tran(self):

@@ -48,7 +48,9 @@ LAEA_WP = "+proj=laea +lat_0=90 +lon_0=0 +ellps=WGS84"
 LAEA_WE = "+proj=laea +lat_0=0 +lon_0=20 +ellps=WGS84"
 AEA_W = "+proj=aea +lat_1=29.5 +lat_2=45.5 +lat_0=23 +lon_0=-96 +x_0=0 +y_0=0 +ellps=GRS80"
 AEA_W1 = "+proj=aea +lat_1=55 +lat_2=55 +lat_0=50 +lon_0=10 +ellps=WGS84"
-ELLIPSOIDAL = [AEA_W, AEA_W1, LAEA_W, LAEA_WP, LAEA_WE, UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
+GEOS_MSG = "+proj=geos +lon_0=0 +h=3.57858e+07  +a=6.37817e+06  +b=6.35658e+06 +no_defs +x_0=-2.2098e+06 +y_0=-3.50297e+06"   # testProjections.cc:69
+GEOS_X = "+proj=geos +lon_0=-75 +h=35786023 +sweep=x +ellps=GRS80"
+ELLIPSOIDAL = [GEOS_MSG, GEOS_X, AEA_W, AEA_W1, LAEA_W, LAEA_WP, LAEA_WE, UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
 
 
 @pytest.fixture(scope="module")
@@ -101,9 +103,12 @@ def test_ellipsoidal_projections_from_geographic_and_back(fa, dst):
     tm = "tmerc" in dst or "utm" in dst
     series = "proj=tmerc" in dst   # Gauss-Krueger truncated; utm and etmerc carry the series to n^6 and hold far out
     lon0 = np.degrees(po._Proj(dst).lam0)
-    lon = np.radians(rng.uniform(lon0 - 12, lon0 + 12, 20000) if series else (rng.uniform(lon0 - 40, lon0 + 40, 20000) if tm else rng.uniform(-60, 80, 20000)))
+    geos = "proj=geos" in dst
+    lon = np.radians(rng.uniform(lon0 - 12, lon0 + 12, 20000) if series else (rng.uniform(lon0 - 40, lon0 + 40, 20000) if tm or geos else rng.uniform(-60, 80, 20000)))
     south = dst == STERE_WS
     lat = np.radians(rng.uniform(-85 if south else (-70 if tm or dst in (MERC_W, LAEA_WE) else 20), -30 if south else 85, 20000))
+    if geos:
+        lat = np.radians(rng.uniform(-60, 60, 20000))   # on the visible disc
     x, y = fa.project_values_host(GEO_W, dst, lon, lat)
     wx, wy = po.transform(GEO_W, dst, lon, lat)
     atol = 2e-6 if dst == TMERC_S else 2e-8   # metres; the spherical form takes acos of nearly 1 at the equator
@@ -332,3 +337,18 @@ def test_wind_to_a_projection_and_back(fa, case, wind):
     assert ok.mean() > 0.05, ok.mean()
     assert np.abs(u2[ok] - wind[0]).max() < delta and np.abs(v2[ok] - wind[1]).max() < delta, \
         (np.abs(u2[ok] - wind[0]).max(), np.abs(v2[ok] - wind[1]).max())
+
+
+@pytest.mark.parametrize("proj", ["+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0", GEOS_MSG])
+def test_reference_conversion_round_trips_on_the_gpu(fa, proj):
+    """test/testProjections.cc:84-124, 168-208: the projection's 10 x 10 mesh at 50 km to longitude / latitude and back
+    within 1e-5 m, here through fimex_amd_project_values; beyond the limb the satellite view yields NaN."""
+    ll = "+proj=lonlat +ellps=sphere +a=6371000 +e=0"
+    x, y = np.meshgrid(np.arange(10) * 50000., np.arange(10) * 50000., indexing="ij")
+    lon, lat = fa.project_values_host(proj, ll, x.ravel(), y.ravel())
+    assert np.all(np.abs(np.degrees(lat)) <= 90.001) and np.all(np.abs(np.degrees(lon)) <= 180.001)
+    bx, by = fa.project_values_host(ll, proj, lon, lat)
+    assert np.abs(bx - x.ravel()).max() < 1e-5 and np.abs(by - y.ravel()).max() < 1e-5
+    if "geos" in proj:
+        hx, hy = fa.project_values_host(ll, proj, np.radians([150., 0.]), np.radians([0., 0.]))
+        assert np.isnan(hx[0]) and np.isnan(hy[0]) and abs(hx[1] + 2.2098e6) < 1e-6

@@ -337,6 +337,25 @@ def test_reference_file_tests_on_the_erai_fixture(golden_dir):
     assert 270 < pts[0, 0] < 280 and np.all(np.isfinite(pts) & (pts > 266) & (pts < 281.1)), pts
 
 
+REF_CONVERSIONS = [   # test/testProjections.cc:84-208: a projection, its 10 x 10 mesh at 50 km, there and back within 1e-5
+    "+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0",
+    "+proj=geos +lon_0=0 +h=3.57858e+07  +a=6.37817e+06  +b=6.35658e+06 +no_defs +x_0=-2.2098e+06 +y_0=-3.50297e+06",
+]
+
+
+@pytest.mark.parametrize("proj", REF_CONVERSIONS)
+def test_reference_conversion_round_trips(proj):
+    """test/testProjections.cc:84-124 / 168-208 (test_conversion, test_conversion_geostationary): x, y = 0 .. 450 km to
+    longitude / latitude (inside +-180.001 / +-90.001 degrees) and back to within 1e-5 m.  (The oblique Mercator case
+    :126-166 is not implemented.)"""
+    ll = "+proj=lonlat +ellps=sphere +a=6371000 +e=0"
+    x, y = np.meshgrid(np.arange(10) * 50000., np.arange(10) * 50000., indexing="ij")
+    lon, lat = po.transform(proj, ll, x.ravel(), y.ravel())
+    assert np.all(np.abs(np.degrees(lat)) <= 90.001) and np.all(np.abs(np.degrees(lon)) <= 180.001)
+    bx, by = po.transform(ll, proj, lon, lat)
+    assert np.abs(bx - x.ravel()).max() < 1e-5 and np.abs(by - y.ravel()).max() < 1e-5
+
+
 # ---------------------------------------------------------------- ellipsoidal projections (SURVEY 8f n2, testInterpolator.cc:422)
 # Worked numerical examples of Snyder, "Map Projections - A Working Manual" (USGS PP 1395), appendix A: the published
 # known answers the PROJ.4 series are checked against in the absence of the library (values in metres, one decimal).

@@ -5,7 +5,7 @@
 // PROJ.4 is a third-party library that is not part of the reference tree; the projections are implemented from their
 // published closed forms on the sphere (Snyder, "Map Projections - A Working Manual", USGS PP 1395) with PROJ.4's
 // conventions at the pj_transform boundary: geographic coordinates in radians, projected x = a * x' + x_0, longitudes
-// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, ob_tran +
+// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, omerc, ob_tran +
 // o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
 // an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
@@ -30,7 +30,7 @@ constexpr double kSpi = 3.14159265359;  // PROJ.4's adjlon threshold
 constexpr double kEps10 = 1e-10;
 constexpr double kDegToRad = .0174532925199432958;  // proj_api.h DEG_TO_RAD
 
-enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea, kGeos };
+enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea, kGeos, kOmerc };
 enum StereMode { kNorth = 0, kSouth, kOblique, kEquatorial };
 
 struct ProjParams {
@@ -44,6 +44,7 @@ struct ProjParams {
     double qp, rq, dd, xmf, ymf, sinb1, cosb1, apa[3];  // laea (aea: dd, and n, c, rho0 of lcc)
     double ec, n2;                // aea
     double radius_g, radius_g_1, radius_p, radius_p2, radius_p_inv2, C;  // geos (flip_axis in mode)
+    double oA, oB, oE, ArB, BrA, rB, singam, cosgam, sinrot, cosrot, v_pole_n, v_pole_s, u_0;  // omerc (no_rot in mode)
     double towgs84[7];            // only compared between the two sides
 };
 
@@ -52,7 +53,7 @@ constexpr Ellipsoid kEllipsoids[] = {
     {"sphere", 6370997.0, true, 6370997.0},  {"WGS84", 6378137.0, false, 298.257223563}, {"GRS80", 6378137.0, false, 298.257222101},
     {"WGS72", 6378135.0, false, 298.26},     {"GRS67", 6378160.0, false, 298.2471674270}, {"bessel", 6377397.155, false, 299.1528128},
     {"intl", 6378388.0, false, 297.},        {"clrk66", 6378206.4, true, 6356583.8},      {"clrk80", 6378249.145, false, 293.4663},
-    {"krass", 6378245.0, false, 298.3},      {"airy", 6377563.396, true, 6356256.910},
+    {"krass", 6378245.0, false, 298.3},      {"airy", 6377563.396, true, 6356256.910},      {"evrstSS", 6377298.556, false, 300.8017},
 };
 
 // pj_tsfn / pj_msfn / pj_phi2 / pj_enfn / pj_mlfn / pj_inv_mlfn
@@ -380,6 +381,56 @@ ProjParams parse_proj4(const char* text)
             p.esp = p.k0;
             p.ml0 = .5 * p.esp;
         }
+    } else if (name == "omerc") {  // PJ_omerc.c setup, central point and azimuth (Snyder's alternate B)
+        p.kind = kOmerc;
+        const bool alp = has("alpha"), gam = has("gamma");
+        if (!alp && !gam) throw Error("omerc is implemented by central point and azimuth (+lonc +alpha / +gamma) only: " + proj4);
+        p.mode = has("no_rot");
+        const bool no_off = has("no_off") || has("no_uoff");
+        double alpha_c = rad("alpha", 0), gamma = rad("gamma", 0), gamma0;
+        const double lamc = rad("lonc", 0), com = std::sqrt(1. - p.es);
+        double D, F;
+        if (std::fabs(p.phi0) > kEps10) {
+            const double sinph0 = std::sin(p.phi0), cosph0 = std::cos(p.phi0);
+            const double con = 1. - p.es * sinph0 * sinph0;
+            p.oB = cosph0 * cosph0;
+            p.oB = std::sqrt(1. + p.es * p.oB * p.oB / (1. - p.es));
+            p.oA = p.oB * p.k0 * com / con;
+            D = p.oB * com / (cosph0 * std::sqrt(con));
+            if ((F = D * D - 1.) <= 0.) F = 0.;
+            else {
+                F = std::sqrt(F);
+                if (p.phi0 < 0.) F = -F;
+            }
+            p.oE = F += D;
+            p.oE *= std::pow(tsfn(p.phi0, sinph0, p.e), p.oB);
+        } else {
+            p.oB = 1. / com;
+            p.oA = p.k0;
+            p.oE = D = F = 1.;
+        }
+        if (alp) {
+            gamma0 = std::asin(std::sin(alpha_c) / D);
+            if (!gam) gamma = alpha_c;
+        } else {
+            alpha_c = std::asin(D * std::sin(gamma0 = gamma));
+        }
+        const double con = std::fabs(alpha_c);
+        if (con <= 1e-7 || std::fabs(con - kPi) <= 1e-7 || std::fabs(std::fabs(p.phi0) - kHalfPi) <= 1e-7)
+            throw Error("omerc: alpha of 0 or 180 degrees, or lat_0 at a pole: " + proj4);
+        p.lam0 = lamc - std::asin(.5 * (F - 1. / F) * std::tan(gamma0)) / p.oB;  // +lon_0 plays no role
+        p.singam = std::sin(gamma0);
+        p.cosgam = std::cos(gamma0);
+        p.sinrot = std::sin(gamma);
+        p.cosrot = std::cos(gamma);
+        p.BrA = 1. / (p.ArB = p.oA * (p.rB = 1. / p.oB));
+        if (no_off) p.u_0 = 0;
+        else {
+            p.u_0 = std::fabs(p.ArB * std::atan2(std::sqrt(D * D - 1.), std::cos(alpha_c)));
+            if (p.phi0 < 0.) p.u_0 = -p.u_0;
+        }
+        p.v_pole_n = p.ArB * std::log(std::tan(kFortPi - .5 * gamma0));
+        p.v_pole_s = p.ArB * std::log(std::tan(kFortPi + .5 * gamma0));
     } else if (name == "geos") {  // PJ_geos.c setup
         p.kind = kGeos;
         const double h = num("h", 0);
@@ -564,6 +615,27 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
                 if (phi < 0.) py = -py;
                 py = p.esp * (py - p.phi0);
             }
+        }
+    } else if (p.kind == kOmerc) {  // PJ_omerc.c e_forward
+        double u, v;
+        bool ok = true;
+        if (fabs(fabs(phi) - kHalfPi) > kEps10) {
+            const double Q = p.oE / pow(tsfn(phi, sin(phi), p.e), p.oB);
+            const double temp = 1. / Q, S = .5 * (Q - temp), T = .5 * (Q + temp);
+            const double V = sin(p.oB * lam), U = (S * p.singam - V * p.cosgam) / T;
+            if (fabs(fabs(U) - 1.0) < kEps10) ok = false;
+            v = 0.5 * p.ArB * log((1. - U) / (1. + U));
+            u = p.ArB * atan2((S * p.cosgam + V * p.singam), cos(p.oB * lam));
+        } else {
+            v = phi > 0 ? p.v_pole_n : p.v_pole_s;
+            u = p.ArB * phi;
+        }
+        if (!ok) { px = NAN; py = NAN; }
+        else if (p.mode) { px = u; py = v; }
+        else {
+            u -= p.u_0;
+            px = v * p.cosrot + u * p.sinrot;
+            py = u * p.cosrot - v * p.sinrot;
         }
     } else if (p.kind == kGeos) {  // PJ_geos.c e_forward (the spherical form is this one with radius_p = 1)
         phi = atan(p.radius_p2 * tan(phi));
@@ -771,6 +843,23 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
             phi = asin(sqrt((1. - h * h) / (1. + g * g)));
             if (ys < 0. && -phi + p.phi0 < 0.) phi = -phi;  // the hemisphere test of PROJ 4.9 (4.8 and older: y < 0 alone, wrong for lat_0 != 0)
             lam = (g != 0. || h != 0.) ? atan2(g, h) : 0.;
+        }
+    } else if (p.kind == kOmerc) {  // PJ_omerc.c e_inverse
+        double u, v;
+        if (p.mode) { v = ys; u = xs; }
+        else {
+            v = xs * p.cosrot - ys * p.sinrot;
+            u = ys * p.cosrot + xs * p.sinrot + p.u_0;
+        }
+        const double Qp = exp(-p.BrA * v), Sp = .5 * (Qp - 1. / Qp), Tp = .5 * (Qp + 1. / Qp);
+        const double Vp = sin(p.BrA * u), Up = (Vp * p.cosgam + Sp * p.singam) / Tp;
+        if (fabs(fabs(Up) - 1.) < kEps10) {
+            lam = 0.;
+            phi = Up < 0. ? -kHalfPi : kHalfPi;
+        } else {
+            phi = p.oE / sqrt((1. + Up) / (1. - Up));
+            phi = phi2(pow(phi, 1. / p.oB), p.e);
+            lam = -p.rB * atan2((Sp * p.cosgam - Vp * p.singam), cos(p.BrA * u));
         }
     } else if (p.kind == kGeos) {  // PJ_geos.c e_inverse
         double Vx = -1.0, Vy, Vz;

@@ -13,7 +13,7 @@ Lambert conformal conic eq. 15-1..15-5; oblique transformation eq. 5-7..5-10b)
 with PROJ.4's conventions: longitude/latitude in radians at the pj_transform
 boundary, x = a*x' + x_0, lam = lon - lon_0 wrapped to [-pi, pi].
 Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered for
-merc, lcc, polar and oblique stere, laea, aea, geos, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
+merc, lcc, polar and oblique stere, laea, aea, geos, omerc, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
 of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
 latitude pass unchanged between the two sides (no datum shift is restated; a pair
@@ -69,6 +69,7 @@ ELLIPSOIDS = {
     "clrk80": (6378249.145, "rf", 293.4663),
     "krass": (6378245.0, "rf", 298.3),
     "airy": (6377563.396, "b", 6356256.910),
+    "evrstSS": (6377298.556, "rf", 300.8017),
 }
 DATUMS = {"WGS84": "WGS84", "NAD83": "GRS80"}  # datums without a grid shift: ellipsoid only
 _UNSUPPORTED = ("geoc", "over", "pm", "axis", "to_meter", "vto_meter", "nadgrids", "geoidgrids",
@@ -222,7 +223,7 @@ class _Proj:
     def _kind(self):
         if self.latlong:
             return "latlong"
-        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea", "geos"):
+        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea", "geos", "omerc"):
             return self.name
         raise NotImplementedError("projection %s" % self.name)
 
@@ -818,6 +819,91 @@ class _Proj:
             phi = np.arctan(vz * np.cos(lam) / vx)
             phi = np.arctan(self.radius_p_inv2 * np.tan(phi))
             return np.where(det < 0., np.nan, lam), np.where(det < 0., np.nan, phi)
+
+    # ---- Hotine oblique Mercator, central point and azimuth (PJ_omerc.c; Snyder eq. 9-11..9-48, alternate B)
+    def _setup_omerc(self):
+        p = self.p
+        if "alpha" not in p and "gamma" not in p:
+            raise NotImplementedError("omerc by two points (+lat_1 +lon_1 +lat_2 +lon_2)")
+        self.no_rot = "no_rot" in p
+        no_off = "no_off" in p or "no_uoff" in p
+        alp, gam = "alpha" in p, "gamma" in p
+        alpha_c, gamma = _rad(p, "alpha"), _rad(p, "gamma")
+        lamc = _rad(p, "lonc")
+        es, e = self.es, self.e
+        com = math.sqrt(1. - es)
+        if abs(self.phi0) > _EPS10:
+            sinph0, cosph0 = math.sin(self.phi0), math.cos(self.phi0)
+            con = 1. - es * sinph0 * sinph0
+            B = cosph0 * cosph0
+            B = math.sqrt(1. + es * B * B / (1. - es))
+            A = B * self.k0 * com / con
+            D = B * com / (cosph0 * math.sqrt(con))
+            F = D * D - 1.
+            F = 0. if F <= 0. else math.copysign(math.sqrt(F), self.phi0)
+            F += D
+            E = F * math.pow(float(tsfn(self.phi0, sinph0, e)), B)
+        else:
+            B, A, E, D, F = 1. / com, self.k0, 1., 1., 1.
+        if alp:
+            gamma0 = math.asin(math.sin(alpha_c) / D)
+            if not gam:
+                gamma = alpha_c
+        else:
+            gamma0 = gamma
+            alpha_c = math.asin(D * math.sin(gamma0))
+        con = abs(alpha_c)
+        if con <= 1e-7 or abs(con - math.pi) <= 1e-7 or abs(abs(self.phi0) - HALFPI) <= 1e-7:
+            raise ValueError("omerc: alpha is 0 or 180 degrees, or lat_0 a pole (PROJ.4 error -32)")
+        self.lam0 = lamc - math.asin(.5 * (F - 1. / F) * math.tan(gamma0)) / B   # +lon_0 plays no role
+        self.B, self.A, self.E = B, A, E
+        self.singam, self.cosgam = math.sin(gamma0), math.cos(gamma0)
+        self.sinrot, self.cosrot = math.sin(gamma), math.cos(gamma)
+        self.rB = 1. / B
+        self.ArB = A * self.rB
+        self.BrA = 1. / self.ArB
+        if no_off:
+            self.u_0 = 0.
+        else:
+            self.u_0 = math.copysign(abs(self.ArB * math.atan2(math.sqrt(D * D - 1.), math.cos(alpha_c))), 1. if self.phi0 >= 0. else -1.)
+        self.v_pole_n = self.ArB * math.log(math.tan(FORTPI - .5 * gamma0))
+        self.v_pole_s = self.ArB * math.log(math.tan(FORTPI + .5 * gamma0))
+
+    def _fwd_omerc(self, lam, phi):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            Q = self.E / np.power(tsfn(phi, np.sin(phi), self.e), self.B)
+            S, T = .5 * (Q - 1. / Q), .5 * (Q + 1. / Q)
+            V = np.sin(self.B * lam)
+            U = (S * self.singam - V * self.cosgam) / T
+            v = .5 * self.ArB * np.log((1. - U) / (1. + U))
+            u = self.ArB * np.arctan2(S * self.cosgam + V * self.singam, np.cos(self.B * lam))
+            bad = np.abs(np.abs(U) - 1.) < _EPS10
+            pole = np.abs(np.abs(phi) - HALFPI) <= _EPS10
+            v = np.where(pole, np.where(phi > 0, self.v_pole_n, self.v_pole_s), v)
+            u = np.where(pole, self.ArB * phi, u)
+            if self.no_rot:
+                x, y = u, v
+            else:
+                u = u - self.u_0
+                x, y = v * self.cosrot + u * self.sinrot, u * self.cosrot - v * self.sinrot
+            return np.where(bad & ~pole, np.nan, x), np.where(bad & ~pole, np.nan, y)
+
+    def _inv_omerc(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.no_rot:
+                v, u = y, x
+            else:
+                v = x * self.cosrot - y * self.sinrot
+                u = y * self.cosrot + x * self.sinrot + self.u_0
+            Qp = np.exp(-self.BrA * v)
+            Sp, Tp = .5 * (Qp - 1. / Qp), .5 * (Qp + 1. / Qp)
+            Vp = np.sin(self.BrA * u)
+            Up = (Vp * self.cosgam + Sp * self.singam) / Tp
+            pole = np.abs(np.abs(Up) - 1.) < _EPS10
+            t = self.E / np.sqrt((1. + Up) / (1. - Up))
+            phi = phi2(np.power(np.where(pole, 1., t), 1. / self.B), self.e)
+            lam = -self.rB * np.arctan2(Sp * self.cosgam - Vp * self.singam, np.cos(self.BrA * u))
+            return np.where(pole, 0., lam), np.where(pole, np.where(Up < 0., -HALFPI, HALFPI), phi)
 
     # ---- general oblique transformation around a geographic "projection" (rotated pole)
     def _setup_ob_tran(self):

@@ -50,6 +50,8 @@ AEA_W = "+proj=aea +lat_1=29.5 +lat_2=45.5 +lat_0=23 +lon_0=-96 +x_0=0 +y_0=0 +e
 AEA_W1 = "+proj=aea +lat_1=55 +lat_2=55 +lat_0=50 +lon_0=10 +ellps=WGS84"
 GEOS_MSG = "+proj=geos +lon_0=0 +h=3.57858e+07  +a=6.37817e+06  +b=6.35658e+06 +no_defs +x_0=-2.2098e+06 +y_0=-3.50297e+06"   # testProjections.cc:69
 GEOS_X = "+proj=geos +lon_0=-75 +h=35786023 +sweep=x +ellps=GRS80"
+OMERC_REF = "+proj=omerc +lonc=5.34065 +lat_0=60.742 +alpha=19.0198 +no_rot   +a=6.37814e+06  +b=6.35675e+06 +no_defs +x_0=-3.86098e+06 +y_0=1.5594e+06"   # testProjections.cc:56
+OMERC_RSO = "+proj=omerc +lat_0=4 +lonc=115 +alpha=53.31582047222222 +gamma=53.13010236111111 +k=0.99984 +x_0=590476.87 +y_0=442857.65 +a=6377298.556 +rf=300.8017"
 ELLIPSOIDAL = [GEOS_MSG, GEOS_X, AEA_W, AEA_W1, LAEA_W, LAEA_WP, LAEA_WE, UTM33, UTM17S, ETMERC, TMERC_S, TMERC_B, STERE_W, STERE_WS, STERE_WP, STERE_WO, LCC_W, LCC_W1, MERC_W]
 
 
@@ -149,7 +151,7 @@ def test_unsupported_projection_strings_fail_loudly(fa):
     for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=0 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84", "+lat_0=3",
                 "+proj=ob_tran +o_proj=stere +R=1", "+proj=ob_tran +o_proj=longlat +o_lat_p=30 +ellps=WGS84", "+proj=merc +ellps=WGS84 +units=km",
                 "+proj=merc +datum=potsdam", "+proj=merc +ellps=nonesuch", "+proj=stere +lat_0=90", "+proj=lcc +lat_1=30 +lat_2=-30 +R=1",
-                "+proj=merc +R=6371000 +pm=oslo", "+proj=omerc +lat_0=60 +R=6371000"):
+                "+proj=merc +R=6371000 +pm=oslo", "+proj=omerc +lat_0=60 +R=6371000", "+proj=sinu +R=6371000"):
         with pytest.raises(fa.FimexAmdError):
             fa.project_values_host(GEO, bad, np.zeros(3), np.zeros(3))
     with pytest.raises(fa.FimexAmdError):  # pj_transform would shift the datum here
@@ -339,9 +341,26 @@ def test_wind_to_a_projection_and_back(fa, case, wind):
         (np.abs(u2[ok] - wind[0]).max(), np.abs(v2[ok] - wind[1]).max())
 
 
-@pytest.mark.parametrize("proj", ["+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0", GEOS_MSG])
+def test_oblique_mercator_on_the_gpu(fa):
+    """The EPSG worked example (Timbalai 1948 / RSO Borneo) and the oracle on a swath of points around each projection's line."""
+    lon, lat = np.radians([115 + 48 / 60 + 19.8196 / 3600]), np.radians([5 + 23 / 60 + 14.1129 / 3600])
+    x, y = fa.project_values_host("+proj=latlong +a=6377298.556 +rf=300.8017", OMERC_RSO, lon, lat)
+    assert abs(x[0] - 679245.73) < 0.01 and abs(y[0] - 596562.78) < 0.01
+    rng = np.random.default_rng(9)
+    for proj, lo, la in ((OMERC_RSO, (108, 120), (0, 8)), (OMERC_REF, (-25, 15), (30, 70))):
+        lon, lat = np.radians(rng.uniform(*lo, 5000)), np.radians(rng.uniform(*la, 5000))
+        x, y = fa.project_values_host(GEO_W, proj, lon, lat)
+        wx, wy = po.transform(GEO_W, proj, lon, lat)
+        np.testing.assert_allclose(x, wx, rtol=2e-12, atol=2e-8); np.testing.assert_allclose(y, wy, rtol=2e-12, atol=2e-8)
+        bx, by = fa.project_values_host(proj, GEO_W, x, y)
+        np.testing.assert_allclose(bx, lon, atol=2e-10); np.testing.assert_allclose(by, lat, atol=2e-10)
+    with pytest.raises(fa.FimexAmdError):   # the two-point form is not implemented
+        fa.project_values_host(GEO_W, "+proj=omerc +lat_0=40 +lat_1=47.5 +lon_1=-122.3 +lat_2=39 +lon_2=-104.5 +ellps=clrk66", lon, lat)
+
+
+@pytest.mark.parametrize("proj", ["+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0", GEOS_MSG, OMERC_REF])
 def test_reference_conversion_round_trips_on_the_gpu(fa, proj):
-    """test/testProjections.cc:84-124, 168-208: the projection's 10 x 10 mesh at 50 km to longitude / latitude and back
+    """test/testProjections.cc:84-208: the projection's 10 x 10 mesh at 50 km to longitude / latitude and back
     within 1e-5 m, here through fimex_amd_project_values; beyond the limb the satellite view yields NaN."""
     ll = "+proj=lonlat +ellps=sphere +a=6371000 +e=0"
     x, y = np.meshgrid(np.arange(10) * 50000., np.arange(10) * 50000., indexing="ij")

@@ -340,14 +340,27 @@ def test_reference_file_tests_on_the_erai_fixture(golden_dir):
 REF_CONVERSIONS = [   # test/testProjections.cc:84-208: a projection, its 10 x 10 mesh at 50 km, there and back within 1e-5
     "+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0",
     "+proj=geos +lon_0=0 +h=3.57858e+07  +a=6.37817e+06  +b=6.35658e+06 +no_defs +x_0=-2.2098e+06 +y_0=-3.50297e+06",
+    "+proj=omerc +lonc=5.34065 +lat_0=60.742 +alpha=19.0198 +no_rot   +a=6.37814e+06  +b=6.35675e+06 +no_defs +x_0=-3.86098e+06 +y_0=1.5594e+06",
 ]
+
+
+def test_hotine_oblique_mercator_epsg_worked_example():
+    """EPSG Guidance Note 7-2, Hotine oblique Mercator, Timbalai 1948 / RSO Borneo: 5 23 14.1129 N, 115 48 19.8196 E maps
+    to E 679245.73, N 596562.78 -- variant A (natural origin: PROJ.4's +no_uoff, FE = FN = 0) and variant B (centre of the
+    projection, Ec 590476.87, Nc 442857.65) alike."""
+    common = "+proj=omerc +lat_0=4 +lonc=115 +alpha=53.31582047222222 +gamma=53.13010236111111 +k=0.99984 +a=6377298.556 +rf=300.8017"
+    lon, lat = np.radians([115 + 48 / 60 + 19.8196 / 3600]), np.radians([5 + 23 / 60 + 14.1129 / 3600])
+    for proj in (common + " +no_uoff", common + " +x_0=590476.87 +y_0=442857.65"):
+        x, y = po.transform("+proj=latlong +a=6377298.556 +rf=300.8017", proj, lon, lat)
+        assert abs(x[0] - 679245.73) < 0.01 and abs(y[0] - 596562.78) < 0.01, (proj, x, y)
+        bl, bp = po.transform(proj, "+proj=latlong +a=6377298.556 +rf=300.8017", x, y)
+        assert abs(bl[0] - lon[0]) < 1e-11 and abs(bp[0] - lat[0]) < 1e-11
 
 
 @pytest.mark.parametrize("proj", REF_CONVERSIONS)
 def test_reference_conversion_round_trips(proj):
-    """test/testProjections.cc:84-124 / 168-208 (test_conversion, test_conversion_geostationary): x, y = 0 .. 450 km to
-    longitude / latitude (inside +-180.001 / +-90.001 degrees) and back to within 1e-5 m.  (The oblique Mercator case
-    :126-166 is not implemented.)"""
+    """test/testProjections.cc:84-208 (test_conversion, test_conversion_oblique_mercator, test_conversion_geostationary): x, y = 0 .. 450 km to
+    longitude / latitude (inside +-180.001 / +-90.001 degrees) and back to within 1e-5 m.  """
     ll = "+proj=lonlat +ellps=sphere +a=6371000 +e=0"
     x, y = np.meshgrid(np.arange(10) * 50000., np.arange(10) * 50000., indexing="ij")
     lon, lat = po.transform(proj, ll, x.ravel(), y.ravel())

@@ -5,7 +5,7 @@
 // PROJ.4 is a third-party library that is not part of the reference tree; the projections are implemented from their
 // published closed forms on the sphere (Snyder, "Map Projections - A Working Manual", USGS PP 1395) with PROJ.4's
 // conventions at the pj_transform boundary: geographic coordinates in radians, projected x = a * x' + x_0, longitudes
-// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, omerc, ob_tran +
+// relative to lon_0 wrapped to [-pi, pi].  Supported: latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, omerc, sinu, cea, ortho, aeqd, nsper, ob_tran +
 // o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
 // an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
@@ -30,7 +30,7 @@ constexpr double kSpi = 3.14159265359;  // PROJ.4's adjlon threshold
 constexpr double kEps10 = 1e-10;
 constexpr double kDegToRad = .0174532925199432958;  // proj_api.h DEG_TO_RAD
 
-enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea, kGeos, kOmerc };
+enum ProjKind { kLatLong = 0, kStere, kLcc, kMerc, kObTran, kTmerc, kEtmerc, kLaea, kAea, kGeos, kOmerc, kSinu, kCea, kOrtho, kAeqd, kNsper };
 enum StereMode { kNorth = 0, kSouth, kOblique, kEquatorial };
 
 struct ProjParams {
@@ -44,6 +44,7 @@ struct ProjParams {
     double qp, rq, dd, xmf, ymf, sinb1, cosb1, apa[3];  // laea (aea: dd, and n, c, rho0 of lcc)
     double ec, n2;                // aea
     double radius_g, radius_g_1, radius_p, radius_p2, radius_p_inv2, C;  // geos (flip_axis in mode)
+    double pn1, pp, rp, pfact;    // nsper (sinph0 / cosph0 and the aspect in mode as for stere; sinu: en; cea: k0, qp, apa)
     double oA, oB, oE, ArB, BrA, rB, singam, cosgam, sinrot, cosrot, v_pole_n, v_pole_s, u_0;  // omerc (no_rot in mode)
     double towgs84[7];            // only compared between the two sides
 };
@@ -381,6 +382,42 @@ ProjParams parse_proj4(const char* text)
             p.esp = p.k0;
             p.ml0 = .5 * p.esp;
         }
+    } else if (name == "sinu") {  // PJ_gn_sinu.c
+        p.kind = kSinu;
+        if (p.es != 0) enfn(p.es, p.en);
+    } else if (name == "cea") {  // PJ_cea.c
+        p.kind = kCea;
+        const double t = rad("lat_ts", 0);
+        p.k0 = std::cos(t);
+        if (p.k0 < 0) throw Error("cea: |lat_ts| > 90: " + proj4);
+        if (p.es != 0) {
+            const double st = std::sin(t);
+            p.k0 /= std::sqrt(1. - p.es * st * st);
+            double t2 = p.es * p.es;  // pj_authset
+            p.apa[0] = p.es * .33333333333333333333 + t2 * .17222222222222222222;
+            p.apa[1] = t2 * .06388888888888888888;
+            t2 *= p.es;
+            p.apa[0] += t2 * .10257936507936507936;
+            p.apa[1] += t2 * .06640211640211640211;
+            p.apa[2] = t2 * .01641501294219154443;
+            p.qp = qsfn(1., p.e, 1. - p.es);
+        }
+    } else if (name == "ortho" || name == "aeqd" || name == "nsper") {  // PJ_ortho.c, PJ_aeqd.c (sphere), PJ_nsper.c
+        p.kind = name == "ortho" ? kOrtho : (name == "aeqd" ? kAeqd : kNsper);
+        if (p.es != 0) throw Error(name + " is implemented on the sphere only: " + proj4);
+        const double t = std::fabs(p.phi0);
+        if (std::fabs(t - kHalfPi) < kEps10) p.mode = p.phi0 < 0 ? kSouth : kNorth;
+        else p.mode = t < kEps10 ? kEquatorial : kOblique;
+        p.sinph0 = std::sin(p.phi0);
+        p.cosph0 = std::cos(p.phi0);
+        if (name == "nsper") {
+            const double height = num("h", 0);
+            if (!(height > 0)) throw Error("nsper needs +h > 0: " + proj4);
+            p.pn1 = height / p.a;
+            p.pp = 1. + p.pn1;
+            p.rp = 1. / p.pp;
+            p.pfact = (p.pp + 1.) / p.pn1;
+        }
     } else if (name == "omerc") {  // PJ_omerc.c setup, central point and azimuth (Snyder's alternate B)
         p.kind = kOmerc;
         const bool alp = has("alpha"), gam = has("gamma");
@@ -616,6 +653,63 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
                 py = p.esp * (py - p.phi0);
             }
         }
+    } else if (p.kind == kSinu) {
+        const double sn = sin(phi), cs = cos(phi);
+        if (p.es != 0) { py = mlfn(phi, sn, cs, p.en); px = lam * cs / sqrt(1. - p.es * sn * sn); }
+        else { px = lam * cs; py = phi; }
+    } else if (p.kind == kCea) {
+        px = p.k0 * lam;
+        py = p.es != 0 ? .5 * qsfn(sin(phi), p.e, 1. - p.es) / p.k0 : sin(phi) / p.k0;
+    } else if (p.kind == kOrtho) {  // PJ_ortho.c s_forward
+        const double cosphi = cos(phi), sinphi = sin(phi);
+        double coslam = cos(lam);
+        bool bad;
+        if (p.mode == kEquatorial) { bad = cosphi * coslam < -kEps10; py = sinphi; }
+        else if (p.mode == kOblique) {
+            bad = p.sinph0 * sinphi + p.cosph0 * cosphi * coslam < -kEps10;
+            py = p.cosph0 * sinphi - p.sinph0 * cosphi * coslam;
+        } else {
+            if (p.mode == kNorth) coslam = -coslam;
+            bad = fabs(phi - p.phi0) - kEps10 > kHalfPi;
+            py = cosphi * coslam;
+        }
+        px = cosphi * sin(lam);
+        if (bad) { px = NAN; py = NAN; }
+    } else if (p.kind == kAeqd) {  // PJ_aeqd.c s_forward
+        const double sinphi = sin(phi), cosphi = cos(phi);
+        double coslam = cos(lam);
+        if (p.mode == kEquatorial || p.mode == kOblique) {
+            py = p.mode == kEquatorial ? cosphi * coslam : p.sinph0 * sinphi + p.cosph0 * cosphi * coslam;
+            if (fabs(fabs(py) - 1.) < 1e-14) {
+                if (py < 0.) { px = NAN; py = NAN; }
+                else { px = 0.; py = 0.; }
+            } else {
+                py = acos(py);
+                py /= sin(py);
+                px = py * cosphi * sin(lam);
+                py *= p.mode == kEquatorial ? sinphi : p.cosph0 * sinphi - p.sinph0 * cosphi * coslam;
+            }
+        } else {
+            if (p.mode == kNorth) { phi = -phi; coslam = -coslam; }
+            if (fabs(phi - kHalfPi) < kEps10) { px = NAN; py = NAN; }
+            else {
+                py = kHalfPi + phi;
+                px = py * sin(lam);
+                py *= coslam;
+            }
+        }
+    } else if (p.kind == kNsper) {  // PJ_nsper.c s_forward (no tilt)
+        const double sinphi = sin(phi), cosphi = cos(phi), coslam = cos(lam);
+        py = p.mode == kOblique ? p.sinph0 * sinphi + p.cosph0 * cosphi * coslam
+             : (p.mode == kEquatorial ? cosphi * coslam : (p.mode == kSouth ? -sinphi : sinphi));
+        if (py < p.rp) { px = NAN; py = NAN; }  // beyond the horizon
+        else {
+            py = p.pn1 / (p.pp - py);
+            px = py * cosphi * sin(lam);
+            if (p.mode == kOblique) py *= p.cosph0 * sinphi - p.sinph0 * cosphi * coslam;
+            else if (p.mode == kEquatorial) py *= sinphi;
+            else py *= cosphi * (p.mode == kNorth ? -coslam : coslam);
+        }
     } else if (p.kind == kOmerc) {  // PJ_omerc.c e_forward
         double u, v;
         bool ok = true;
@@ -843,6 +937,97 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
             phi = asin(sqrt((1. - h * h) / (1. + g * g)));
             if (ys < 0. && -phi + p.phi0 < 0.) phi = -phi;  // the hemisphere test of PROJ 4.9 (4.8 and older: y < 0 alone, wrong for lat_0 != 0)
             lam = (g != 0. || h != 0.) ? atan2(g, h) : 0.;
+        }
+    } else if (p.kind == kSinu) {
+        if (p.es != 0) {
+            phi = inv_mlfn(ys, p.es, p.en);
+            const double ab = fabs(phi);
+            if (ab < kHalfPi) {
+                const double sn = sin(phi);
+                lam = xs * sqrt(1. - p.es * sn * sn) / cos(phi);
+            } else if (ab - kEps10 < kHalfPi) lam = 0.;
+            else { lam = NAN; phi = NAN; }
+        } else {
+            phi = ys;
+            lam = xs / cos(ys);
+        }
+    } else if (p.kind == kCea) {
+        lam = xs / p.k0;
+        if (p.es != 0) {
+            double q = 2. * ys * p.k0 / p.qp;
+            q = q > 1 ? 1 : (q < -1 ? -1 : q);
+            const double beta = asin(q), t = beta + beta;
+            phi = beta + p.apa[0] * sin(t) + p.apa[1] * sin(t + t) + p.apa[2] * sin(t + t + t);
+        } else {
+            ys *= p.k0;
+            const double t = fabs(ys);
+            if (t - kEps10 <= 1.) phi = t >= 1. ? (ys < 0. ? -kHalfPi : kHalfPi) : asin(ys);
+            else { phi = NAN; lam = NAN; }
+        }
+    } else if (p.kind == kOrtho) {  // PJ_ortho.c s_inverse
+        const double rh = hypot(xs, ys);
+        double sinc = rh;
+        if (sinc - 1. > kEps10) { phi = NAN; lam = NAN; }
+        else {
+            if (sinc > 1.) sinc = 1.;
+            const double cosc = sqrt(1. - sinc * sinc);
+            if (fabs(rh) <= kEps10) { phi = p.phi0; lam = 0.; }
+            else {
+                if (p.mode == kNorth) { ys = -ys; phi = acos(sinc); }
+                else if (p.mode == kSouth) phi = -acos(sinc);
+                else {
+                    if (p.mode == kEquatorial) { phi = ys * sinc / rh; xs *= sinc; ys = cosc * rh; }
+                    else {
+                        phi = cosc * p.sinph0 + ys * sinc * p.cosph0 / rh;
+                        ys = (cosc - p.sinph0 * phi) * rh;
+                        xs *= sinc * p.cosph0;
+                    }
+                    phi = fabs(phi) >= 1. ? (phi < 0. ? -kHalfPi : kHalfPi) : asin(phi);
+                }
+                lam = (ys == 0. && (p.mode == kOblique || p.mode == kEquatorial)) ? (xs == 0. ? 0. : (xs < 0. ? -kHalfPi : kHalfPi)) : atan2(xs, ys);
+            }
+        }
+    } else if (p.kind == kAeqd) {  // PJ_aeqd.c s_inverse
+        double c_rh = hypot(xs, ys);
+        if (c_rh - kEps10 > kPi) { phi = NAN; lam = NAN; }
+        else if (c_rh < kEps10) { phi = p.phi0; lam = 0.; }
+        else {
+            if (c_rh > kPi) c_rh = kPi;
+            if (p.mode == kOblique || p.mode == kEquatorial) {
+                const double sinc = sin(c_rh), cosc = cos(c_rh);
+                double arg;
+                if (p.mode == kEquatorial) { arg = ys * sinc / c_rh; xs *= sinc; ys = cosc * c_rh; }
+                else {
+                    arg = cosc * p.sinph0 + ys * sinc * p.cosph0 / c_rh;
+                    arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
+                    ys = (cosc - p.sinph0 * arg) * c_rh;  // sin(asin(arg))
+                    xs *= sinc * p.cosph0;
+                }
+                arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
+                phi = asin(arg);
+                lam = ys == 0. ? 0. : atan2(xs, ys);
+            } else if (p.mode == kNorth) { phi = kHalfPi - c_rh; lam = atan2(xs, -ys); }
+            else { phi = c_rh - kHalfPi; lam = atan2(xs, ys); }
+        }
+    } else if (p.kind == kNsper) {  // PJ_nsper.c s_inverse
+        const double rh = hypot(xs, ys);
+        double sinz = 1. - rh * rh * p.pfact;
+        if (sinz < 0.) { phi = NAN; lam = NAN; }
+        else if (fabs(rh) <= kEps10) { lam = 0.; phi = p.phi0; }
+        else {
+            sinz = (p.pp - sqrt(sinz)) / (p.pn1 / rh + rh / p.pn1);
+            const double cosz = sqrt(1. - sinz * sinz);
+            if (p.mode == kOblique) {
+                phi = asin(cosz * p.sinph0 + ys * sinz * p.cosph0 / rh);
+                ys = (cosz - p.sinph0 * sin(phi)) * rh;
+                xs *= sinz * p.cosph0;
+            } else if (p.mode == kEquatorial) {
+                phi = asin(ys * sinz / rh);
+                ys = cosz * rh;
+                xs *= sinz;
+            } else if (p.mode == kNorth) { phi = asin(cosz); ys = -ys; }
+            else phi = -asin(cosz);
+            lam = atan2(xs, ys);
         }
     } else if (p.kind == kOmerc) {  // PJ_omerc.c e_inverse
         double u, v;

@@ -292,7 +292,7 @@ int fimex_amd_get_values_linear_d_device(const double* d_infieldA, const double*
 
 /* ----------------------------------- plan building across projections (8f n2) */
 /* The reference calls PROJ.4 (pj_init_plus / pj_transform) here; this library carries its own projections:
- * latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, omerc, ob_tran with o_proj=longlat (radians at this boundary for
+ * latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, omerc, sinu, cea, ortho, aeqd, nsper, ob_tran with o_proj=longlat (radians at this boundary for
  * geographic and rotated coordinates, as PROJ.4's legacy API), on a sphere (+R, +a +e=0, +ellps=sphere) or an ellipsoid
  * (+ellps, +datum=WGS84|NAD83, +a with +b/+rf/+f/+e/+es).  Strings that need a datum shift, +units, +pm, +axis or another
  * projection make the call fail with a message. */

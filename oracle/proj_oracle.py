@@ -13,7 +13,7 @@ Lambert conformal conic eq. 15-1..15-5; oblique transformation eq. 5-7..5-10b)
 with PROJ.4's conventions: longitude/latitude in radians at the pj_transform
 boundary, x = a*x' + x_0, lam = lon - lon_0 wrapped to [-pi, pi].
 Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered for
-merc, lcc, polar and oblique stere, laea, aea, geos, omerc, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
+merc, lcc, polar and oblique stere, laea, aea, geos, omerc, sinu, cea, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
 of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
 latitude pass unchanged between the two sides (no datum shift is restated; a pair
@@ -223,7 +223,7 @@ class _Proj:
     def _kind(self):
         if self.latlong:
             return "latlong"
-        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea", "geos", "omerc"):
+        if self.name in ("stere", "lcc", "ob_tran", "merc", "tmerc", "etmerc", "utm", "laea", "aea", "geos", "omerc", "sinu", "cea", "ortho", "aeqd", "nsper"):
             return self.name
         raise NotImplementedError("projection %s" % self.name)
 
@@ -904,6 +904,200 @@ class _Proj:
             phi = phi2(np.power(np.where(pole, 1., t), 1. / self.B), self.e)
             lam = -self.rB * np.arctan2(Sp * self.cosgam - Vp * self.singam, np.cos(self.BrA * u))
             return np.where(pole, 0., lam), np.where(pole, np.where(Up < 0., -HALFPI, HALFPI), phi)
+
+    # ---- the remaining projections of the reference's src/coordSys: sinusoidal, cylindrical equal-area, orthographic,
+    # azimuthal equidistant, vertical near-side perspective (Snyder ch. 30, 10, 20, 25, 23; the last three on the sphere only,
+    # as in PROJ.4 4.x apart from aeqd's geodesic form)
+    def _aspect(self):
+        t = abs(self.phi0)
+        if abs(t - HALFPI) < _EPS10:
+            return "S" if self.phi0 < 0 else "N"
+        return "E" if t < _EPS10 else "O"
+
+    def _setup_sinu(self):
+        if self.es != 0.:
+            self.en = enfn(self.es)
+
+    def _fwd_sinu(self, lam, phi):
+        s, c = np.sin(phi), np.cos(phi)
+        if self.es != 0.:
+            return lam * c / np.sqrt(1. - self.es * s * s), mlfn(phi, s, c, self.en)
+        return lam * c, phi
+
+    def _inv_sinu(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.es != 0.:
+                phi = inv_mlfn(y, self.es, self.en)
+                s = np.sin(phi)
+                lam = x * np.sqrt(1. - self.es * s * s) / np.cos(phi)
+                a = np.abs(phi)
+                return np.where(a < HALFPI, lam, np.where(a - _EPS10 < HALFPI, 0., np.nan)), np.where(a - _EPS10 < HALFPI, phi, np.nan)
+            return x / np.cos(y), y
+
+    def _setup_cea(self):
+        t = _rad(self.p, "lat_ts")
+        self.k0 = math.cos(t)
+        if self.es != 0.:
+            st = math.sin(t)
+            self.k0 /= math.sqrt(1. - self.es * st * st)
+            es = self.es
+            self.apa = [es * .33333333333333333333 + es * es * .17222222222222222222 + es ** 3 * .10257936507936507936,
+                        es * es * .06388888888888888888 + es ** 3 * .06640211640211640211, es ** 3 * .01641501294219154443]
+            self.qp = float(self._qsfn(1.))
+
+    def _fwd_cea(self, lam, phi):
+        if self.es != 0.:
+            return self.k0 * lam, .5 * self._qsfn(np.sin(phi)) / self.k0
+        return self.k0 * lam, np.sin(phi) / self.k0
+
+    def _inv_cea(self, x, y):
+        with np.errstate(invalid="ignore"):
+            if self.es != 0.:
+                beta = np.arcsin(np.clip(2. * y * self.k0 / self.qp, -1., 1.))
+                t = beta + beta
+                return x / self.k0, beta + self.apa[0] * np.sin(t) + self.apa[1] * np.sin(t + t) + self.apa[2] * np.sin(t + t + t)
+            y = y * self.k0
+            t = np.abs(y)
+            phi = np.where(t >= 1., np.where(y < 0., -HALFPI, HALFPI), np.arcsin(np.clip(y, -1., 1.)))
+            return np.where(t - _EPS10 <= 1., x / self.k0, np.nan), np.where(t - _EPS10 <= 1., phi, np.nan)
+
+    def _sphere_only(self):
+        if self.es != 0.:
+            raise NotImplementedError("%s on an ellipsoid" % self.name)
+        self.mode = self._aspect()
+        self.sinph0, self.cosph0 = math.sin(self.phi0), math.cos(self.phi0)
+
+    def _setup_ortho(self):
+        self._sphere_only()
+
+    def _fwd_ortho(self, lam, phi):
+        cosphi, coslam, sinphi = np.cos(phi), np.cos(lam), np.sin(phi)
+        if self.mode == "E":
+            bad, y = cosphi * coslam < -_EPS10, sinphi
+        elif self.mode == "O":
+            bad = self.sinph0 * sinphi + self.cosph0 * cosphi * coslam < -_EPS10
+            y = self.cosph0 * sinphi - self.sinph0 * cosphi * coslam
+        else:
+            if self.mode == "N":
+                coslam = -coslam
+            bad, y = np.abs(phi - self.phi0) - _EPS10 > HALFPI, cosphi * coslam
+        return np.where(bad, np.nan, cosphi * np.sin(lam)), np.where(bad, np.nan, y)
+
+    def _inv_ortho(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rh = np.hypot(x, y)
+            bad = rh - 1. > _EPS10
+            sinc = np.minimum(rh, 1.)
+            cosc = np.sqrt(1. - sinc * sinc)
+            if self.mode == "N":
+                y, phi = -y, np.arccos(sinc)
+            elif self.mode == "S":
+                phi = -np.arccos(sinc)
+            else:
+                if self.mode == "E":
+                    phi = y * sinc / rh
+                    x, y = x * sinc, cosc * rh
+                else:
+                    phi = cosc * self.sinph0 + y * sinc * self.cosph0 / rh
+                    y = (cosc - self.sinph0 * phi) * rh
+                    x = x * sinc * self.cosph0
+                phi = np.where(np.abs(phi) >= 1., np.where(phi < 0., -HALFPI, HALFPI), np.arcsin(np.clip(phi, -1., 1.)))
+            if self.mode in ("E", "O"):
+                lam = np.where(y == 0., np.where(x == 0., 0., np.where(x < 0., -HALFPI, HALFPI)), np.arctan2(x, y))
+            else:
+                lam = np.arctan2(x, y)
+            centre = np.abs(rh) <= _EPS10
+            return np.where(bad, np.nan, np.where(centre, 0., lam)), np.where(bad, np.nan, np.where(centre, self.phi0, phi))
+
+    def _setup_aeqd(self):
+        self._sphere_only()
+
+    def _fwd_aeqd(self, lam, phi):
+        sinphi, cosphi, coslam = np.sin(phi), np.cos(phi), np.cos(lam)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.mode in ("E", "O"):
+                y = cosphi * coslam if self.mode == "E" else self.sinph0 * sinphi + self.cosph0 * cosphi * coslam
+                edge = np.abs(np.abs(y) - 1.) < 1e-14
+                k = np.arccos(np.clip(y, -1., 1.))
+                k = k / np.sin(k)
+                x = k * cosphi * np.sin(lam)
+                yy = k * (sinphi if self.mode == "E" else self.cosph0 * sinphi - self.sinph0 * cosphi * coslam)
+                return np.where(edge, np.where(y < 0., np.nan, 0.), x), np.where(edge, np.where(y < 0., np.nan, 0.), yy)
+            if self.mode == "N":
+                phi, coslam = -phi, -coslam
+            bad = np.abs(phi - HALFPI) < _EPS10
+            r = HALFPI + phi
+            return np.where(bad, np.nan, r * np.sin(lam)), np.where(bad, np.nan, r * coslam)
+
+    def _inv_aeqd(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c_rh = np.hypot(x, y)
+            bad = c_rh - _EPS10 > math.pi
+            c_rh = np.minimum(c_rh, math.pi)
+            centre = c_rh < _EPS10
+            if self.mode in ("E", "O"):
+                sinc, cosc = np.sin(c_rh), np.cos(c_rh)
+                if self.mode == "E":
+                    phi = np.arcsin(np.clip(y * sinc / c_rh, -1., 1.))
+                    x, y = x * sinc, cosc * c_rh
+                else:
+                    phi = np.arcsin(np.clip(cosc * self.sinph0 + y * sinc * self.cosph0 / c_rh, -1., 1.))
+                    y = (cosc - self.sinph0 * np.sin(phi)) * c_rh
+                    x = x * sinc * self.cosph0
+                lam = np.where(y == 0., 0., np.arctan2(x, y))
+            elif self.mode == "N":
+                phi, lam = HALFPI - c_rh, np.arctan2(x, -y)
+            else:
+                phi, lam = c_rh - HALFPI, np.arctan2(x, y)
+            return np.where(bad, np.nan, np.where(centre, 0., lam)), np.where(bad, np.nan, np.where(centre, self.phi0, phi))
+
+    def _setup_nsper(self):
+        self._sphere_only()
+        height = float(self.p.get("h", 0.))
+        if height <= 0.:
+            raise ValueError("nsper needs +h > 0 (PROJ.4 error -30)")
+        self.pn1 = height / self.a
+        self.pp = 1. + self.pn1
+        self.rp = 1. / self.pp
+        self.hh = 1. / self.pn1
+        self.pfact = (self.pp + 1.) * self.hh
+
+    def _fwd_nsper(self, lam, phi):
+        sinphi, cosphi, coslam = np.sin(phi), np.cos(phi), np.cos(lam)
+        y = {"O": self.sinph0 * sinphi + self.cosph0 * cosphi * coslam, "E": cosphi * coslam, "S": -sinphi, "N": sinphi}[self.mode]
+        bad = y < self.rp
+        with np.errstate(invalid="ignore", divide="ignore"):
+            k = self.pn1 / (self.pp - y)
+            x = k * cosphi * np.sin(lam)
+            if self.mode == "O":
+                yy = k * (self.cosph0 * sinphi - self.sinph0 * cosphi * coslam)
+            elif self.mode == "E":
+                yy = k * sinphi
+            else:
+                yy = k * cosphi * (-coslam if self.mode == "N" else coslam)
+        return np.where(bad, np.nan, x), np.where(bad, np.nan, yy)
+
+    def _inv_nsper(self, x, y):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rh = np.hypot(x, y)
+            sinz = 1. - rh * rh * self.pfact
+            bad = sinz < 0.
+            sinz = (self.pp - np.sqrt(sinz)) / (self.pn1 / rh + rh / self.pn1)
+            cosz = np.sqrt(1. - sinz * sinz)
+            if self.mode == "O":
+                phi = np.arcsin(np.clip(cosz * self.sinph0 + y * sinz * self.cosph0 / rh, -1., 1.))
+                y = (cosz - self.sinph0 * np.sin(phi)) * rh
+                x = x * sinz * self.cosph0
+            elif self.mode == "E":
+                phi = np.arcsin(np.clip(y * sinz / rh, -1., 1.))
+                y, x = cosz * rh, x * sinz
+            elif self.mode == "N":
+                phi, y = np.arcsin(cosz), -y
+            else:
+                phi = -np.arcsin(cosz)
+            lam = np.arctan2(x, y)
+            centre = np.abs(rh) <= _EPS10
+            return np.where(bad, np.nan, np.where(centre, 0., lam)), np.where(bad, np.nan, np.where(centre, self.phi0, phi))
 
     # ---- general oblique transformation around a geographic "projection" (rotated pole)
     def _setup_ob_tran(self):

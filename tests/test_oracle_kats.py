@@ -337,6 +337,26 @@ def test_reference_file_tests_on_the_erai_fixture(golden_dir):
     assert 270 < pts[0, 0] < 280 and np.all(np.isfinite(pts) & (pts > 266) & (pts < 281.1)), pts
 
 
+SNYDER_MORE = [   # (geographic side, projection, (lon, lat), (x, y), tolerance): the worked examples of the remaining projections
+    ("+proj=latlong +R=1", "+proj=sinu +R=1 +lon_0=-90", (-75., -50.), (0.1682814, -0.8726646), 1e-7),
+    ("+proj=latlong +ellps=clrk66", "+proj=sinu +ellps=clrk66 +lon_0=-90", (-75., -50.), (1075471.5, -5540628.0), 0.1),
+    ("+proj=latlong +R=1", "+proj=cea +R=1 +lat_ts=30 +lon_0=-75", (80., 35.), (2.3428242, 0.6623090), 1e-7),
+    ("+proj=latlong +ellps=clrk66", "+proj=cea +ellps=clrk66 +lat_ts=5 +lon_0=-75", (-78., 5.), (-332699.8, 554248.5), 0.1),
+    ("+proj=latlong +R=1", "+proj=ortho +R=1 +lat_0=40 +lon_0=-100", (-110., 30.), (-0.1503837, -0.1651911), 1e-7),
+    ("+proj=latlong +R=3", "+proj=aeqd +R=3 +lat_0=40 +lon_0=-100", (100., -20.), (-5.8311398, 5.5444634), 1e-7),
+    ("+proj=latlong +R=6371000", "+proj=nsper +R=6371000 +h=500000 +lat_0=39 +lon_0=-77", (-74., 41.), (247194.09, 222485.96), 0.01),
+]
+
+
+@pytest.mark.parametrize("geo,proj,lonlat,xy,tol", SNYDER_MORE)
+def test_remaining_projections_reproduce_snyders_worked_examples(geo, proj, lonlat, xy, tol):
+    lon, lat = np.radians([lonlat[0]]), np.radians([lonlat[1]])
+    x, y = po.transform(geo, proj, lon, lat)
+    assert abs(x[0] - xy[0]) < tol and abs(y[0] - xy[1]) < tol, (x, y)
+    bl, bp = po.transform(proj, geo, x, y)
+    np.testing.assert_allclose([bl[0], bp[0]], [lon[0], lat[0]], atol=1e-9)
+
+
 REF_CONVERSIONS = [   # test/testProjections.cc:84-208: a projection, its 10 x 10 mesh at 50 km, there and back within 1e-5
     "+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0",
     "+proj=geos +lon_0=0 +h=3.57858e+07  +a=6.37817e+06  +b=6.35658e+06 +no_defs +x_0=-2.2098e+06 +y_0=-3.50297e+06",

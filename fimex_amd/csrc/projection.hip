@@ -9,8 +9,9 @@
 // o_proj=longlat; on the sphere and (except ob_tran and the equatorial stereographic, where PROJ.4 releases differ) on
 // an ellipsoid given by +ellps / +datum=WGS84|NAD83 / +a with +b, +rf, +f, +e or +es, with the series PROJ.4 4.x uses
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
-// two sides: a pair of strings that would make pj_transform shift the datum is refused, like everything else not
-// implemented (+units, +to_meter, +pm, +axis, +geoc, +over, grid shifts).
+// two sides unless both name a datum (+datum, +towgs84) and the two differ: then pj_datum_transform's three- or
+// seven-parameter shift is applied at height 0.  Everything else not implemented is refused (+units, +to_meter, +pm,
+// +axis, +geoc, +over, grid shifts).
 #include "plan.hpp"
 
 #include <cmath>
@@ -46,7 +47,8 @@ struct ProjParams {
     double radius_g, radius_g_1, radius_p, radius_p2, radius_p_inv2, C;  // geos (flip_axis in mode)
     double pn1, pp, rp, pfact;    // nsper (sinph0 / cosph0 and the aspect in mode as for stere; sinu: en; cea: k0, qp, apa)
     double oA, oB, oE, ArB, BrA, rB, singam, cosgam, sinrot, cosrot, v_pole_n, v_pole_s, u_0;  // omerc (no_rot in mode)
-    double towgs84[7];            // only compared between the two sides
+    double towgs84[7];            // pj_datum_set: dx dy dz (m), rx ry rz (rad), scale factor
+    int datumType, doShift;       // 0 unknown, 1 three parameters, 2 seven, 3 WGS84; doShift: set on both sides of a pair that needs pj_datum_transform
 };
 
 struct Ellipsoid { const char* name; double a; bool byB; double shape; };  // pj_ellps.c
@@ -241,18 +243,31 @@ ProjParams parse_proj4(const char* text)
     // pj_ell_set: an explicit +a wins over the one +ellps implies; the shape is the first of +es +e +rf +f +b
     p.a = 1;
     p.datum = has("datum") || has("towgs84");
+    if (has("datum") && !has("towgs84")) {  // pj_datums.c (entries without a grid)
+        const std::string& d = par["datum"];
+        if (d == "WGS84" || d == "NAD83") par["towgs84"] = "0,0,0";
+        else if (d == "GGRS87") par["towgs84"] = "-199.87,74.79,246.62";
+        else if (d == "potsdam") par["towgs84"] = "598.1,73.7,418.2,0.202,0.045,-2.455,6.7";
+        else throw Error("datum not implemented: " + proj4);
+    }
     if (has("towgs84")) {
         std::istringstream list(par["towgs84"]);
         std::string item;
         for (int i = 0; i < 7 && std::getline(list, item, ','); ++i) {
             try { p.towgs84[i] = std::stod(item); } catch (...) { throw Error("+towgs84 is not a list of numbers: " + proj4); }
         }
+        if (p.towgs84[3] != 0 || p.towgs84[4] != 0 || p.towgs84[5] != 0 || p.towgs84[6] != 0) {
+            p.datumType = 2;
+            for (int i = 3; i < 6; ++i) p.towgs84[i] *= 4.84813681109535993589914102357e-6;  // SEC_TO_RAD
+            p.towgs84[6] = p.towgs84[6] / 1000000.0 + 1;
+        } else p.datumType = 1;
     }
     if (has("R")) p.a = num("R", 1);
     else {
         if (has("datum") && !has("ellps")) {
             if (par["datum"] == "WGS84") par["ellps"] = "WGS84";
-            else if (par["datum"] == "NAD83") par["ellps"] = "GRS80";
+            else if (par["datum"] == "NAD83" || par["datum"] == "GGRS87") par["ellps"] = "GRS80";
+            else if (par["datum"] == "potsdam") par["ellps"] = "bessel";
             else throw Error("datum not implemented: " + proj4);
         }
         if (has("ellps")) {
@@ -280,6 +295,9 @@ ProjParams parse_proj4(const char* text)
         }
     }
     p.e = std::sqrt(p.es);
+    if (p.datumType == 1 && p.towgs84[0] == 0 && p.towgs84[1] == 0 && p.towgs84[2] == 0 && p.a == 6378137.0 &&
+        std::fabs(p.es - 0.006694379990) < 0.000000000050)
+        p.datumType = 3;  // pj_init: PJD_WGS84
     p.lam0 = rad("lon_0", 0);
     p.phi0 = rad("lat_0", 0);
     p.x0 = num("x_0", 0);
@@ -1184,23 +1202,77 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
     lat = phi;
 }
 
-// pj_transform shifts the datum when both sides name one and they differ (pj_compare_datums); that is not implemented
+// pj_datum_transform applies when both sides name a datum and pj_compare_datums finds them different
 struct ProjPair { ProjParams src, dst; };
 ProjPair parse_pair(const char* projIn, const char* projOut)
 {
-    const ProjPair pp{parse_proj4(projIn), parse_proj4(projOut)};
-    bool sameShift = true;
-    for (int i = 0; i < 7; ++i) sameShift = sameShift && pp.src.towgs84[i] == pp.dst.towgs84[i];
-    if (pp.src.datum && pp.dst.datum && (pp.src.a != pp.dst.a || pp.src.es != pp.dst.es || !sameShift))
-        throw Error(std::string("a datum shift is not implemented: ") + projIn + " -> " + projOut);
+    ProjPair pp{parse_proj4(projIn), parse_proj4(projOut)};
+    const ProjParams &a = pp.src, &b = pp.dst;
+    if (a.datumType != 0 && b.datumType != 0) {
+        bool same = a.datumType == b.datumType && a.a == b.a && std::fabs(a.es - b.es) <= 0.000000000050;
+        const int nPar = a.datumType == 1 ? 3 : (a.datumType == 2 ? 7 : 0);
+        for (int i = 0; i < nPar; ++i) same = same && a.towgs84[i] == b.towgs84[i];
+        const bool params = a.datumType == 1 || a.datumType == 2 || b.datumType == 1 || b.datumType == 2;
+        pp.src.doShift = pp.dst.doShift = !same && (a.es != b.es || a.a != b.a || params);  // either side may be the source of a call
+    }
     return pp;
 }
 
-// pj_transform(src, dst) on one point (geodetic longitude and latitude pass unchanged)
+// geodetic (height 0) -> geocentric -> WGS84 -> the other datum -> geodetic (pj_datum_transform, pj_geocentric_to_wgs84 /
+// _from_wgs84, geocent.c's iteration: at most 30 rounds, 1e-12)
+__device__ void datum_shift(const ProjParams& src, const ProjParams& dst, double& lon, double& lat)
+{
+    const double sinlat = sin(lat), coslat = cos(lat);
+    const double Rn = src.a / sqrt(1.0 - src.es * sinlat * sinlat);
+    double X = Rn * coslat * cos(lon), Y = Rn * coslat * sin(lon), Z = (Rn * (1 - src.es)) * sinlat;
+    const double* v = src.towgs84;
+    if (src.datumType == 1) { X += v[0]; Y += v[1]; Z += v[2]; }
+    else if (src.datumType == 2) {
+        const double xo = v[6] * (X - v[5] * Y + v[4] * Z) + v[0], yo = v[6] * (v[5] * X + Y - v[3] * Z) + v[1],
+                     zo = v[6] * (-v[4] * X + v[3] * Y + Z) + v[2];
+        X = xo; Y = yo; Z = zo;
+    }
+    v = dst.towgs84;
+    if (dst.datumType == 1) { X -= v[0]; Y -= v[1]; Z -= v[2]; }
+    else if (dst.datumType == 2) {
+        const double xt = (X - v[0]) / v[6], yt = (Y - v[1]) / v[6], zt = (Z - v[2]) / v[6];
+        X = xt + v[5] * yt - v[4] * zt;
+        Y = -v[5] * xt + yt + v[3] * zt;
+        Z = v[4] * xt - v[3] * yt + zt;
+    }
+    // pj_Convert_Geocentric_To_Geodetic
+    const double a = dst.a, es = dst.es, P = sqrt(X * X + Y * Y), RR = sqrt(X * X + Y * Y + Z * Z);
+    if (P / a < 1.E-12) {
+        lon = 0.;
+        if (RR / a < 1.E-12) { lat = kHalfPi; return; }
+    } else {
+        lon = atan2(Y, X);
+    }
+    const double CT = Z / RR, ST = P / RR;
+    double RX = 1.0 / sqrt(1.0 - es * (2.0 - es) * ST * ST);
+    double CPHI0 = ST * (1.0 - es) * RX, SPHI0 = CT * RX, CPHI, SPHI, SDPHI;
+    int iter = 0;
+    do {
+        ++iter;
+        const double RN = a / sqrt(1.0 - es * SPHI0 * SPHI0);
+        const double Height = P * CPHI0 + Z * SPHI0 - RN * (1.0 - es * SPHI0 * SPHI0);
+        const double RK = es * RN / (RN + Height);
+        RX = 1.0 / sqrt(1.0 - RK * (2.0 - RK) * ST * ST);
+        CPHI = ST * (1.0 - RK) * RX;
+        SPHI = CT * RX;
+        SDPHI = SPHI * CPHI0 - CPHI * SPHI0;
+        CPHI0 = CPHI;
+        SPHI0 = SPHI;
+    } while (SDPHI * SDPHI > 1.E-24 && iter < 30);
+    lat = atan(SPHI / fabs(CPHI));
+}
+
+// pj_transform(src, dst) on one point
 __device__ __forceinline__ void transform_point(const ProjParams& src, const ProjParams& dst, double& x, double& y)
 {
     double lon, lat;
     proj_inverse(src, x, y, lon, lat);
+    if (src.doShift) datum_shift(src, dst, lon, lat);
     proj_forward(dst, lon, lat, x, y);
 }
 

@@ -294,8 +294,9 @@ int fimex_amd_get_values_linear_d_device(const double* d_infieldA, const double*
 /* The reference calls PROJ.4 (pj_init_plus / pj_transform) here; this library carries its own projections:
  * latlong/longlat, stere, lcc, merc, tmerc, etmerc, utm, laea, aea, geos, omerc, sinu, cea, ortho, aeqd, nsper, ob_tran with o_proj=longlat (radians at this boundary for
  * geographic and rotated coordinates, as PROJ.4's legacy API), on a sphere (+R, +a +e=0, +ellps=sphere) or an ellipsoid
- * (+ellps, +datum=WGS84|NAD83, +a with +b/+rf/+f/+e/+es).  Strings that need a datum shift, +units, +pm, +axis or another
- * projection make the call fail with a message. */
+ * (+ellps, +datum=WGS84|NAD83, +a with +b/+rf/+f/+e/+es).  Three- and seven-parameter datum shifts (+towgs84, +datum=WGS84|NAD83|GGRS87|potsdam)
+ * are applied as pj_transform does; strings that need a grid shift, +units, +pm, +axis or another projection make the call
+ * fail with a message. */
 /** mifi_project_values, include/fimex/interpolation.h / src/interpolation.c:1158-1197: n points in place. */
 int fimex_amd_project_values_host(const char* proj_input, const char* proj_output, double* in_out_x_vals, double* in_out_y_vals, size_t num);
 int fimex_amd_project_values_device(const char* proj_input, const char* proj_output, double* d_x_vals, double* d_y_vals, size_t num, void* stream);

@@ -16,8 +16,9 @@ Ellipsoids (+ellps, +datum=WGS84/NAD83, +a with +b/+rf/+f/+e/+es) are covered fo
 merc, lcc, polar and oblique stere, laea, aea, geos, omerc, sinu, cea, tmerc, etmerc and utm (the UTM zone 33 / WGS84 string
 of test/testInterpolator.cc:422) with the series PROJ.4 4.x uses (Snyder eq. 7-7,
 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21, 3-26); geodetic longitude and
-latitude pass unchanged between the two sides (no datum shift is restated; a pair
-of strings that would need one is refused).
+latitude pass unchanged between the two sides unless both name a datum (+datum, +towgs84)
+and the two differ: then the three- or seven-parameter shift of pj_datum_transform is applied
+through geocentric coordinates at height 0 (grid shifts are refused).
 
 Pins (tests/test_oracle_kats.py): tests/golden/coordTest.nc stores 2-D
 longitude/latitude for its 11x11 polar-stereographic grid (121 points);
@@ -71,7 +72,9 @@ ELLIPSOIDS = {
     "airy": (6377563.396, "b", 6356256.910),
     "evrstSS": (6377298.556, "rf", 300.8017),
 }
-DATUMS = {"WGS84": "WGS84", "NAD83": "GRS80"}  # datums without a grid shift: ellipsoid only
+DATUMS = {"WGS84": "WGS84", "NAD83": "GRS80", "GGRS87": "GRS80", "potsdam": "bessel"}  # pj_datums.c entries without a grid
+DATUM_SHIFTS = {"WGS84": "0,0,0", "NAD83": "0,0,0", "GGRS87": "-199.87,74.79,246.62", "potsdam": "598.1,73.7,418.2,0.202,0.045,-2.455,6.7"}
+_SEC_TO_RAD = 4.84813681109535993589914102357e-6
 _UNSUPPORTED = ("geoc", "over", "pm", "axis", "to_meter", "vto_meter", "nadgrids", "geoidgrids",
                 "R_A", "R_V", "R_a", "R_g", "R_h", "R_lat_a", "R_lat_g")
 
@@ -121,13 +124,73 @@ def _ellipsoid(p):
     return a, es
 
 
-def has_datum(p):
-    return "datum" in p or "towgs84" in p
+def datum_of(p, a, es):
+    """pj_datum_set + the WGS84 test of pj_init: (type, seven parameters); type 0 unknown, 1 three-parameter, 2 seven-parameter
+    (position vector: rotations in radians, scale as a factor), 3 WGS84."""
+    text = p.get("towgs84")
+    if text is None and "datum" in p:
+        text = DATUM_SHIFTS[p["datum"]]
+    if text is None:
+        return 0, [0.] * 7
+    v = ([float(t) for t in text.split(",")] + [0.] * 7)[:7]
+    if any(v[3:]):
+        return 2, v[:3] + [r * _SEC_TO_RAD for r in v[3:6]] + [v[6] / 1e6 + 1.]
+    if not any(v[:3]) and a == 6378137.0 and abs(es - 0.006694379990) < 0.000000000050:
+        return 3, v
+    return 1, v
 
 
-def _towgs84(p):
-    vals = [float(v) for v in p["towgs84"].split(",")] if "towgs84" in p else []
-    return (vals + [0.] * 7)[:7]
+def geodetic_to_geocentric(lon, lat, h, a, es):
+    n = a / np.sqrt(1. - es * np.sin(lat) ** 2)
+    return (n + h) * np.cos(lat) * np.cos(lon), (n + h) * np.cos(lat) * np.sin(lon), (n * (1. - es) + h) * np.sin(lat)
+
+
+def geocentric_to_geodetic(x, y, z, a, es):
+    """Fixed point of tan(lat) = (Z + es N sin(lat)) / P (Bowring's relation, iterated to convergence) -- not the loop of
+    PROJ.4's geocent.c, which the device code follows; the two meet below 1e-12 rad."""
+    p = np.hypot(x, y)
+    lat = np.arctan2(z, p * (1. - es))
+    for _ in range(12):
+        n = a / np.sqrt(1. - es * np.sin(lat) ** 2)
+        lat = np.arctan2(z + es * n * np.sin(lat), p)
+    n = a / np.sqrt(1. - es * np.sin(lat) ** 2)
+    h = np.where(np.abs(np.cos(lat)) > 1e-8, p / np.cos(lat) - n, np.abs(z) - n * (1. - es))
+    return np.arctan2(y, x), lat, h
+
+
+def to_wgs84(kind, v, x, y, z):
+    if kind == 1:
+        return x + v[0], y + v[1], z + v[2]
+    if kind == 2:   # pj_geocentric_to_wgs84, position vector rotation
+        return (v[6] * (x - v[5] * y + v[4] * z) + v[0], v[6] * (v[5] * x + y - v[3] * z) + v[1], v[6] * (-v[4] * x + v[3] * y + z) + v[2])
+    return x, y, z
+
+
+def from_wgs84(kind, v, x, y, z):
+    if kind == 1:
+        return x - v[0], y - v[1], z - v[2]
+    if kind == 2:   # pj_geocentric_from_wgs84
+        xt, yt, zt = (x - v[0]) / v[6], (y - v[1]) / v[6], (z - v[2]) / v[6]
+        return xt + v[5] * yt - v[4] * zt, -v[5] * xt + yt + v[3] * zt, v[4] * xt - v[3] * yt + zt
+    return x, y, z
+
+
+def datum_transform(ps, pd, lon, lat):
+    """pj_datum_transform on geodetic coordinates at height 0 (the reference passes z = 0 and ignores what comes back)."""
+    ks, vs = datum_of(ps.p, ps.a, ps.es)
+    kd, vd = datum_of(pd.p, pd.a, pd.es)
+    if ks == 0 or kd == 0:
+        return lon, lat
+    same = ks == kd and ps.a == pd.a and abs(ps.es - pd.es) <= 5e-11 and (ks == 3 or vs[:3 if ks == 1 else 7] == vd[:3 if ks == 1 else 7])
+    if same:
+        return lon, lat
+    if ps.es == pd.es and ps.a == pd.a and ks not in (1, 2) and kd not in (1, 2):
+        return lon, lat
+    x, y, z = geodetic_to_geocentric(lon, lat, 0., ps.a, ps.es)
+    x, y, z = to_wgs84(ks, vs, x, y, z)
+    x, y, z = from_wgs84(kd, vd, x, y, z)
+    lo, la, _ = geocentric_to_geodetic(x, y, z, pd.a, pd.es)
+    return lo, la
 
 
 def tsfn(phi, sinphi, e):
@@ -1160,9 +1223,8 @@ class _Proj:
 def transform(src, dst, x, y):
     """pj_transform(src, dst, ...): coordinates of src -> coordinates of dst (no datum shift)."""
     ps, pd = _Proj(src), _Proj(dst)
-    if has_datum(ps.p) and has_datum(pd.p) and (ps.a != pd.a or ps.es != pd.es or _towgs84(ps.p) != _towgs84(pd.p)):
-        raise NotImplementedError("a datum shift between %r and %r" % (src, dst))
     lon, lat = ps.inverse(x, y)
+    lon, lat = datum_transform(ps, pd, lon, lat)
     return pd.forward(lon, lat)
 
 

@@ -159,13 +159,41 @@ def test_axes_between_an_ellipsoid_and_a_sphere(fa):
 def test_unsupported_projection_strings_fail_loudly(fa):
     for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=0 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84", "+lat_0=3",
                 "+proj=ob_tran +o_proj=stere +R=1", "+proj=ob_tran +o_proj=longlat +o_lat_p=30 +ellps=WGS84", "+proj=merc +ellps=WGS84 +units=km",
-                "+proj=merc +datum=potsdam", "+proj=merc +ellps=nonesuch", "+proj=stere +lat_0=90", "+proj=lcc +lat_1=30 +lat_2=-30 +R=1",
+                "+proj=merc +datum=NAD27", "+proj=merc +ellps=nonesuch", "+proj=stere +lat_0=90", "+proj=lcc +lat_1=30 +lat_2=-30 +R=1",
                 "+proj=merc +R=6371000 +pm=oslo", "+proj=omerc +lat_0=60 +R=6371000", "+proj=ortho +lat_0=40 +ellps=WGS84", "+proj=nsper +lat_0=40 +R=6371000",
                 "+proj=moll +R=6371000"):
         with pytest.raises(fa.FimexAmdError):
             fa.project_values_host(GEO, bad, np.zeros(3), np.zeros(3))
-    with pytest.raises(fa.FimexAmdError):  # pj_transform would shift the datum here
-        fa.project_values_host(GEO_W, "+proj=utm +zone=33 +ellps=bessel +towgs84=598.1,73.7,418.2,0.202,0.045,-2.455,6.7", np.zeros(3), np.zeros(3))
+    with pytest.raises(fa.FimexAmdError):  # grid shifts
+        fa.project_values_host(GEO_W, "+proj=latlong +ellps=clrk66 +nadgrids=conus", np.zeros(3), np.zeros(3))
+
+
+def test_datum_shifts_on_the_gpu(fa):
+    """pj_datum_transform between sides that both name a datum: three and seven parameters, through projections, both ways,
+    against the oracle (whose geocentric steps reproduce the EPSG worked examples) -- and nothing when one side names none."""
+    rng = np.random.default_rng(3)
+    lon, lat = np.radians(rng.uniform(-10, 30, 5000)), np.radians(rng.uniform(35, 70, 5000))
+    cases_ = [("+proj=latlong +datum=WGS84", "+proj=latlong +datum=potsdam"),
+              ("+proj=latlong +datum=WGS84", "+proj=utm +zone=33 +ellps=intl +towgs84=-87,-98,-121"),                 # ED50
+              ("+proj=latlong +ellps=bessel +towgs84=598.1,73.7,418.2,0.202,0.045,-2.455,6.7", "+proj=etmerc +lat_0=0 +lon_0=9 +k=1 +x_0=3500000 +datum=potsdam"),   # Gauss-Krueger zone 3
+              ("+proj=latlong +datum=GGRS87", "+proj=stere +lat_0=90 +lon_0=0 +lat_ts=60 +datum=WGS84"),
+              ("+proj=latlong +datum=WGS84", "+proj=latlong +datum=NAD83")]
+    for src, dst in cases_:
+        x, y = fa.project_values_host(src, dst, lon, lat)
+        wx, wy = po.transform(src, dst, lon, lat)
+        scale = 1.0 if "latlong" in dst else 6.4e6
+        np.testing.assert_allclose(x, wx, rtol=0, atol=2e-12 * scale); np.testing.assert_allclose(y, wy, rtol=0, atol=2e-12 * scale)
+        bx, by = fa.project_values_host(dst, src, x, y)
+        np.testing.assert_allclose(bx, lon, atol=2e-9); np.testing.assert_allclose(by, lat, atol=2e-9)
+    moved = fa.project_values_host("+proj=latlong +datum=WGS84", "+proj=latlong +datum=potsdam", lon, lat)
+    assert 1e-5 < np.abs(moved[0] - lon).max() < 3e-4
+    same = fa.project_values_host("+proj=latlong +datum=WGS84", "+proj=latlong +ellps=bessel", lon, lat)
+    assert np.array_equal(same[0], lon) and np.array_equal(same[1], lat)
+    # the mesh form shifts as well
+    ax, ay = np.linspace(3e5, 7e5, 41), np.linspace(55e5, 60e5, 31)
+    gx, gy = fa.project_axes_host("+proj=utm +zone=32 +datum=potsdam", "+proj=latlong +datum=WGS84", ax, ay)
+    wx, wy = po.project_axes("+proj=utm +zone=32 +datum=potsdam", "+proj=latlong +datum=WGS84", ax, ay)
+    np.testing.assert_allclose(gx.ravel(), wx, atol=2e-12); np.testing.assert_allclose(gy.ravel(), wy, atol=2e-12)
 
 
 @pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])

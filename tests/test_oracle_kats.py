@@ -357,6 +357,33 @@ def test_remaining_projections_reproduce_snyders_worked_examples(geo, proj, lonl
     np.testing.assert_allclose([bl[0], bp[0]], [lon[0], lat[0]], atol=1e-9)
 
 
+def test_datum_shifts_against_the_epsg_worked_examples():
+    """EPSG Guidance Note 7-2: geographic <-> geocentric (WGS84: 53 48 33.820 N, 2 07 46.380 E, 73.0 m = X 3771793.968,
+    Y 140253.342, Z 5124304.349), geocentric translations WGS84 -> ED50 (+84.87, +96.49, +116.95: 53 48 36.565 N,
+    2 07 51.477 E, 28.02 m) and the position-vector transformation WGS72 -> WGS84."""
+    lat, lon = math.radians(53 + 48 / 60 + 33.820 / 3600), math.radians(2 + 7 / 60 + 46.380 / 3600)
+    es84 = 0.0066943799901413165
+    X, Y, Z = po.geodetic_to_geocentric(lon, lat, 73.0, 6378137.0, es84)
+    assert abs(X - 3771793.968) < 1e-3 and abs(Y - 140253.342) < 1e-3 and abs(Z - 5124304.349) < 1e-3
+    f = 1 / 297.
+    lo, la, h = po.geocentric_to_geodetic(np.array([X + 84.87]), np.array([Y + 96.49]), np.array([Z + 116.95]), 6378388.0, f * (2 - f))
+    assert abs(math.degrees(la[0]) - (53 + 48 / 60 + 36.565 / 3600)) < 2e-7 and abs(math.degrees(lo[0]) - (2 + 7 / 60 + 51.477 / 3600)) < 2e-7
+    assert abs(h[0] - 28.02) < 0.01
+    v = [0., 0., 4.5, 0., 0., 0.554 * po._SEC_TO_RAD, 1 + 0.219e-6]
+    x, y, z = po.to_wgs84(2, v, 3657660.66, 255768.55, 5201382.11)
+    assert abs(x - 3657660.78) < 0.01 and abs(y - 255778.43) < 0.01 and abs(z - 5201387.75) < 0.01
+    # pj_transform: only when both sides name a datum; the way back undoes it (to the 1e-8 degree the approximate inverse leaves)
+    lon2, lat2 = np.radians([10., 13.4]), np.radians([50., 52.5])
+    a = po.transform("+proj=latlong +datum=WGS84", "+proj=latlong +datum=potsdam", lon2, lat2)
+    assert 1e-5 < abs(a[0][0] - lon2[0]) < 1e-4 and 1e-5 < abs(a[1][0] - lat2[0]) < 1e-4     # a hundred metres or so
+    b = po.transform("+proj=latlong +datum=potsdam", "+proj=latlong +datum=WGS84", *a)
+    np.testing.assert_allclose(b[0], lon2, atol=1e-9); np.testing.assert_allclose(b[1], lat2, atol=1e-9)
+    c = po.transform("+proj=latlong +datum=WGS84", "+proj=latlong +ellps=bessel", lon2, lat2)       # no datum on one side: untouched
+    assert np.array_equal(c[0], lon2) and np.array_equal(c[1], lat2)
+    d = po.transform("+proj=latlong +datum=WGS84", "+proj=latlong +datum=NAD83", lon2, lat2)        # zero shift between two ellipsoids
+    assert np.abs(d[1] - lat2).max() < 1e-10 and np.abs(d[0] - lon2).max() < 1e-15
+
+
 REF_CONVERSIONS = [   # test/testProjections.cc:84-208: a projection, its 10 x 10 mesh at 50 km, there and back within 1e-5
     "+proj=stere +lat_0=90 +lon_0=-32 +lat_ts=60 +ellps=sphere +a=6371000 +e=0",
     "+proj=geos +lon_0=0 +h=3.57858e+07  +a=6.37817e+06  +b=6.35658e+06 +no_defs +x_0=-2.2098e+06 +y_0=-3.50297e+06",
@@ -497,9 +524,8 @@ def test_ellipsoid_parameters_follow_pj_ell_set():
     assert P("+proj=merc +a=6378137 +f=0.0033528106647474805").es == pytest.approx(0.0066943799901413165, rel=1e-12)
     assert P("+proj=merc +R=6371000 +ellps=WGS84").es == 0.0                 # +R wins over everything
     for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=61 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84",
-                "+proj=merc +ellps=WGS84 +units=km", "+proj=merc +datum=potsdam"):
+                "+proj=merc +ellps=WGS84 +units=km", "+proj=merc +datum=NAD27"):
         with pytest.raises((NotImplementedError, ValueError)):
             P(bad)
-    with pytest.raises(NotImplementedError):   # would need a datum shift
-        po.transform("+proj=latlong +datum=WGS84", "+proj=utm +zone=33 +ellps=bessel +towgs84=598.1,73.7,418.2,0.202,0.045,-2.455,6.7",
-                     np.zeros(1), np.zeros(1))
+    with pytest.raises((NotImplementedError, KeyError)):   # grid shifts are not restated
+        po.transform("+proj=latlong +datum=WGS84", "+proj=latlong +ellps=clrk66 +nadgrids=conus", np.zeros(1), np.zeros(1))

@@ -889,6 +889,15 @@ struct Handoff {
 };
 __device__ __forceinline__ unsigned int hand_tag(uint32_t band, uint32_t cols) { return ((band + 1) << 19) | cols; }
 
+// e = (f1 + f2 + f3 + f4) * 0.25 - f of interpolation.c:1332: the float sum times the double constant, minus the float
+// as double, rounded to float.  One fused multiply-add gives the same bits with a third of the dependent operations: the
+// product is exact either way, and the difference of two floats either fits a double exactly (exponents at most 29
+// apart: then both paths round the same exact value once) or is dominated by the larger one so completely that both
+// round to it; infinities and NaN take the same way through both.  (-ffp-contract=off forbids the compiler to fuse on
+// its own; this fusion is deliberate.)  tests/test_gpu_parity.py::test_sor_error_is_the_reference_expression walks the
+// exponent gaps.
+__device__ __forceinline__ float sor_error(float sum, float center) { return __builtin_fmaf(sum, 0.25f, -center); }
+
 // one band of one sweep, executed by one wave.  Global memory is touched only in the "event" between two 16-step
 // chunks: loads issued there are consumed one event later, stores are never waited for (the sweep ends with a
 // workgroup barrier); the 16 steps in between run on registers and LDS.
@@ -1096,7 +1105,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 const float downLast = lane_value(dsel, (dBase + k) & 63);
                 if (lane == L) down = downLast;
                 const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
-                const float e = (float)((double)(((right + prevRes) + down) + up) * 0.25 - (double)center);  // interpolation.c:1332
+                const float e = sor_error(((right + prevRes) + down) + up, center);  // interpolation.c:1332
                 const float res = center + e * wv;                                                           // :1333
                 rc[k] = res;
                 prevRes = res;
@@ -1135,7 +1144,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 if (lane == L) down = downLast;
                 const float left = (x == 1) ? left0 : prevRes;
                 const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
-                const float e = (float)((double)(((right + left) + down) + up) * 0.25 - (double)center);  // interpolation.c:1332
+                const float e = sor_error(((right + left) + down) + up, center);  // interpolation.c:1332
                 const float res = active ? center + e * wv : center;                                      // :1333
                 rc[k] = res;
                 prevRes = res;
@@ -1165,7 +1174,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             if (lane == L) down = downLast;
             const float left = (x == 1) ? left0 : prevRes;
             const float wv = ((mw >> (xp & 31)) & 1u) ? wInt : wZero;
-            const float e = (float)((double)(((right + left) + down) + up) * 0.25 - (double)center);  // interpolation.c:1332
+            const float e = sor_error(((right + left) + down) + up, center);  // interpolation.c:1332
             const float res = center + e * wv;                                                        // :1333
             if (active) {
                 ringRow[xp & (kRingW - 1)] = res;

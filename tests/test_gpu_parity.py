@@ -302,6 +302,23 @@ def test_stored_type_regrid_on_random_shapes(fa):
         plan.close()
 
 
+def test_sor_error_is_the_reference_expression(fa):
+    """fill2d's step takes one fused multiply-add where the reference goes through double (fill.hip, sor_error): fields whose
+    neighbours lie up to 60 binades apart, subnormals and values next to the float range's end put every regime of the two
+    roundings through the kernel; the oracle computes the reference's expression as written."""
+    rng = np.random.default_rng(1333)
+    for case, (lo, hi) in enumerate(((-30, 30), (-60, 0), (0, 38), (-149, -110), (-5, 5))):
+        ny, nx = 70, 150
+        f = (rng.uniform(1, 2, (ny, nx)) * 2.0 ** rng.integers(lo, hi, (ny, nx)) * rng.choice([-1, 1], (ny, nx))).astype(np.float32)
+        f[rng.random((ny, nx)) < 0.2] = np.nan
+        f = f[None]
+        for corr in (1.0, 1.6):
+            with np.errstate(all="ignore"):
+                want, wn, rc = oracle.fill2d(f[0], 1e-9, corr, 7)
+            got, nch = fa.fill2d_host(f, 1e-9, corr, 7)
+            assert rc == oracle.OK and nch[0] == wn and cases.same(got[0], want), (case, corr, cases.describe_mismatch(got[0], want))
+
+
 def test_fills_on_random_shapes(fa, monkeypatch):
     """Forty slices of random size, hole pattern and parameters through both band geometries and all three fills:
     every width class of the systolic kernels (narrower than a chunk, one band, ragged last band, several hand-off

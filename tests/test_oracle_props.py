@@ -369,3 +369,49 @@ def test_flann_translate_is_the_closest_cell_within_max_dist():
     assert inside.any() and (~inside).any()
     assert np.all(px[~inside] == -1000)
     assert ((px[inside] == best[inside] % 50) & (py[inside] == best[inside] // 50)).mean() > 0.999
+
+
+def _round_fraction_to_f32(q):
+    """Correctly rounded (nearest, ties to even) float32 of an exact rational."""
+    from fractions import Fraction
+    if q == 0:
+        return np.float32(0.0)
+    sign = -1 if q < 0 else 1
+    q = abs(q)
+    e = q.numerator.bit_length() - q.denominator.bit_length()
+    if Fraction(2) ** e > q:
+        e -= 1
+    e = max(e, -126)                                  # subnormals share the exponent of the smallest normal
+    scaled = q / Fraction(2) ** (e - 23)              # integer part = 24-bit significand
+    n = scaled.numerator // scaled.denominator
+    rem = scaled - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+        n += 1
+    return np.float32(sign * float(n) * 2.0 ** (e - 23))   # n < 2^25 and the power of two: exact in double, then exact in float32
+
+
+def test_sor_error_in_double_equals_one_fused_operation():
+    """interpolation.c:1332 computes e = (float)((double)sum * 0.25 - (double)f).  The device takes fmaf(sum, 0.25f, -f): the
+    exactly rounded value of sum / 4 - f.  The two agree for every pair of floats (fill.hip, sor_error); here the C
+    expression, as numpy evaluates it, is compared with the exact rational result rounded once -- over random pairs at every
+    exponent gap from -45 to +45 binades, near-cancellations, halfway cases and subnormal results."""
+    from fractions import Fraction
+    rng = np.random.default_rng(1332)
+    pairs = []
+    for gap in range(-45, 46):
+        for _ in range(40):
+            s = np.float32(rng.uniform(1, 2) * 2.0 ** int(rng.integers(-20, 20)) * rng.choice([-1, 1]))
+            f = np.float32(rng.uniform(1, 2) * 2.0 ** (np.log2(abs(float(s))) // 1 - 2 + gap) * rng.choice([-1, 1]))
+            pairs.append((s, f))
+    for _ in range(2000):                              # sum / 4 next to f: cancellation down to single ulps
+        f = np.float32(rng.normal(280, 20))
+        s = np.float32(4 * float(f)) + np.float32(rng.integers(-8, 9)) * np.spacing(np.float32(4 * float(f)))
+        pairs.append((np.float32(s), f))
+    for _ in range(500):                               # results in the subnormal range
+        f = np.float32(rng.uniform(1, 2) * 2.0 ** -130)
+        pairs.append((np.float32(rng.uniform(1, 2) * 2.0 ** -128), f))
+    for s, f in pairs:
+        with np.errstate(all="ignore"):
+            c_expression = np.float32(np.float64(s) * 0.25 - np.float64(f))
+        exact = _round_fraction_to_f32(Fraction(float(s)) / 4 - Fraction(float(f)))
+        assert c_expression.tobytes() == exact.tobytes() or (c_expression == 0 and exact == 0), (s, f, c_expression, exact)

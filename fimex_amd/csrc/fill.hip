@@ -916,7 +916,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     const uint32_t C = nx - 2;                                   // interior columns 1 .. C
     const uint32_t xpEnd = C + L;                                // last skewed column with work
     float* ringRow = ring + lane * kPitch;
-    const float* ringBelow = ring + min(lane + 1, (uint32_t)kWave - 1) * kPitch;
+    // the ring's row below lane L (row nrow <= 64) is virtual: the first row of the band below, written chunk by chunk from
+    // the 64-column blocks downA / downB, so that the last lane reads its "down" like every other lane
+    const float* ringBelow = ring + min(lane + 1, L + 1) * kPitch;
+    float* ringVirtual = ring + (L + 1) * kPitch;
     const float left0 = f[(size_t)y * nx];                       // border column 0, not touched by the sweep
     const uint32_t* mrow = maskS + (size_t)y * mws;
     // the band's rows plus the row above and the row below as one buffer: masked lanes use an out-of-range offset
@@ -1093,17 +1096,21 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             const uint32_t kSwitch = (L - xpc) & 63;
             const bool switches = kSwitch < (uint32_t)kCh;  // xpc + kSwitch > L holds: xpc >= 64 > L - kSwitch
             const int dBase = (int)((xpc - L) & 63);
+            {   // the chunk's kCh values of the row below the band into the virtual ring row (lane j: step j)
+                const uint32_t j = lane & (kCh - 1);
+                const int src = (int)((dBase + j) & 63);   // (the choice of the block is the reading lane's, not the source lane's)
+                const float fromA = __shfl(downA, src), fromB = __shfl(downB, src);  // by all lanes: a shuffle under a divergent branch misses its source lanes
+                const float vd = (switches && j >= kSwitch) ? fromB : fromA;
+                if (lane < (uint32_t)kCh) ringVirtual[(xpc + 1 + j) & (kRingW - 1)] = vd;
+            }
 #pragma unroll
             for (int k = 0; k < kCh; ++k) {
                 const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
-                float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                const float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;
                 float up = lane_from_above(prevRes);
                 const float upFirst = lane_value(upCur, (int)(up0 + k));
                 if (lane == 0) up = upFirst;
-                const float dsel = (switches && (uint32_t)k >= kSwitch) ? downB : downA;
-                const float downLast = lane_value(dsel, (dBase + k) & 63);
-                if (lane == L) down = downLast;
                 const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
                 const float e = sor_error(((right + prevRes) + down) + up, center);  // interpolation.c:1332
                 const float res = center + e * wv;                                                           // :1333
@@ -1128,20 +1135,23 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             const uint32_t kSwitch = (L - xpc) & 63;                           // step at which the last lane enters the next 64-column block
             const bool switches = kSwitch < (uint32_t)kCh && xpc + kSwitch > L;
             const int dBase = (int)((xpc - L) & 63);                           // column of the last lane within its block (valid when xpc >= L)
+            {   // the virtual ring row, as in the interior path (columns before the last lane's first one are never used)
+                const uint32_t j = lane & (kCh - 1);
+                const int src = (int)((xpc + j >= L) ? ((dBase + j) & 63) : 0);
+                const float fromA = __shfl(downA, src), fromB = __shfl(downB, src);  // by all lanes: a shuffle under a divergent branch misses its source lanes
+                const float vd = (switches && j >= kSwitch) ? fromB : fromA;
+                if (lane < (uint32_t)kCh) ringVirtual[(xpc + 1 + j) & (kRingW - 1)] = vd;
+            }
 #pragma unroll
             for (int k = 0; k < kCh; ++k) {
                 const int x = x0 + k;
                 const bool active = rowValid && x >= 1 && x <= (int)C;
                 const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
-                float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                const float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;
                 float up = lane_from_above(prevRes);
                 const float upFirst = lane_value(upCur, (int)(up0 + k));
                 if (lane == 0) up = upFirst;
-                const bool afterSwitch = switches && (uint32_t)k >= kSwitch;
-                const float dsel = afterSwitch ? downB : downA;
-                const float downLast = lane_value(dsel, (xpc + k >= L) ? ((dBase + k) & 63) : 0);
-                if (lane == L) down = downLast;
                 const float left = (x == 1) ? left0 : prevRes;
                 const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
                 const float e = sor_error(((right + left) + down) + up, center);  // interpolation.c:1332
@@ -1197,7 +1207,7 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
     extern __shared__ __attribute__((aligned(16))) float smem[];  // rings [16][64][33] floats, hand-off [16][2][192] + counters
     float* rings = smem;
     Handoff hand;
-    hand.data = smem + kV2Waves * kWave * kPitch;
+    hand.data = smem + kV2Waves * (kWave + 1) * kPitch;   // every wave's ring has a 65th row: the row below the band
     hand.produced = reinterpret_cast<unsigned int*>(hand.data + kV2Waves * 2 * kHandW);
     hand.consumed = hand.produced + kV2Waves * 2;
     const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
@@ -1219,7 +1229,7 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
     const float crtest = (float)(crit * a.corrEff);
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
     const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
-    float* ring = rings + wave * kWave * kPitch;
+    float* ring = rings + wave * (kWave + 1) * kPitch;
     for (unsigned long long n = 0; n < a.maxLoop; ++n) {
         const bool check = (n < (a.maxLoop - 5)) && (n % 10 == 0);
         int bad = 0;
@@ -1872,7 +1882,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         const int geometry = tuning("FILL_GEOMETRY", 0);  // 0: by batch size, 1: 16 x 16, 2: 8 x 32
         const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 48));
         auto launch = [&](auto kernel, int ch, int waves) {
-            const size_t ldsBytes = (size_t)waves * kWave * (2 * ch + 1) * sizeof(float) + (size_t)waves * 2 * kHandW * sizeof(float) +
+            const size_t ldsBytes = (size_t)waves * (kWave + 1) * (2 * ch + 1) * sizeof(float) + (size_t)waves * 2 * kHandW * sizeof(float) +
                                     (size_t)waves * 4 * sizeof(unsigned int);
             allow_dynamic_lds(reinterpret_cast<const void*>(kernel), ldsBytes);
             kernel<<<dim3((uint32_t)nz), waves * kWave, ldsBytes, stream>>>(a);

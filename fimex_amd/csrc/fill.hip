@@ -871,6 +871,12 @@ __device__ __forceinline__ float lane_from_above(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
+// the same with lane 0 (which has no lane above) receiving `first`: the DPP move leaves lanes without a source at the
+// old value of the destination, so the separate select for lane 0 is not needed
+__device__ __forceinline__ float lane_from_above_or(float v, float first)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
 // value held by lane `idx` (wave-uniform index) broadcast through an SGPR
 __device__ __forceinline__ float lane_value(float v, int idx)
 {
@@ -1108,9 +1114,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
                 const float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;
-                float up = lane_from_above(prevRes);
-                const float upFirst = lane_value(upCur, (int)(up0 + k));
-                if (lane == 0) up = upFirst;
+                const float up = lane_from_above_or(prevRes, lane_value(upCur, (int)(up0 + k)));
                 const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
                 const float e = sor_error(((right + prevRes) + down) + up, center);  // interpolation.c:1332
                 const float res = center + e * wv;                                                           // :1333
@@ -1149,9 +1153,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
                 const float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;
-                float up = lane_from_above(prevRes);
-                const float upFirst = lane_value(upCur, (int)(up0 + k));
-                if (lane == 0) up = upFirst;
+                const float up = lane_from_above_or(prevRes, lane_value(upCur, (int)(up0 + k)));
                 const float left = (x == 1) ? left0 : prevRes;
                 const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
                 const float e = sor_error(((right + left) + down) + up, center);  // interpolation.c:1332
@@ -1670,9 +1672,8 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 const float right = (k < kCreepCh - 1) ? rc[k + 1] : ringRow[rNext];
                 float down = (k < kCreepCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;
-                float up = lane_from_above(prevRes), wu = lane_from_above(prevW);
-                const float upFirst = lane_value(upCur, (int)(up0 + k)), wuFirst = lane_value(upWCur, (int)(up0 + k));
-                if (lane == 0) { up = upFirst; wu = wuFirst; }
+                const float up = lane_from_above_or(prevRes, lane_value(upCur, (int)(up0 + k)));
+                const float wu = lane_from_above_or(prevW, lane_value(upWCur, (int)(up0 + k)));
                 const bool after = switches && (uint32_t)k >= kSwitch;
                 const float dsel = after ? downB : downA, dwsel = after ? downWB : downWA;
                 const float downLast = lane_value(dsel, (dBase + k) & 63), wdLast = lane_value(dwsel, (dBase + k) & 63);
@@ -1717,9 +1718,8 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             const float right = ringRow[rp];
             float down = ringBelow[rp];
             const float center = prevRight;
-            float up = lane_from_above(prevRes), wu = lane_from_above(prevW);
-            const float upFirst = lane_value(upCur, (int)(xp & 63)), wuFirst = lane_value(upWCur, (int)(xp & 63));
-            if (lane == 0) { up = upFirst; wu = wuFirst; }
+            const float up = lane_from_above_or(prevRes, lane_value(upCur, (int)(xp & 63)));
+            const float wu = lane_from_above_or(prevW, lane_value(upWCur, (int)(xp & 63)));
             const int dIdx = (int)((xp >= L) ? ((xp - L) & 63) : 0);
             const float downLast = lane_value(downA, dIdx), wdLast = lane_value(downWA, dIdx);
             if (lane == L) { down = downLast; wd = wdLast; }

@@ -907,11 +907,13 @@ __device__ __forceinline__ float sor_error(float sum, float center) { return __b
 // one band of one sweep, executed by one wave.  Global memory is touched only in the "event" between two 16-step
 // chunks: loads issued there are consumed one event later, stores are never waited for (the sweep ends with a
 // workgroup barrier); the 16 steps in between run on registers and LDS.
-template <int CH, int WAVES>
+// CHECK: a sweep that also tests convergence (every tenth, :1339-1360); the other nine carry no trace of the test
+template <int CH, int WAVES, bool CHECK>
 __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ maskS, float* ring, Handoff hand, uint32_t b,
-                            uint32_t nx, uint32_t ny, uint32_t mws, float wInt, float wZero, bool check, float crtest, int& bad)
+                            uint32_t nx, uint32_t ny, uint32_t mws, float wInt, float wZero, float crtest, int& bad)
 {
     FILL_GEOMETRY(CH, WAVES);
+    constexpr bool check = CHECK;
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t y0 = 1 + kWave * b;
@@ -1238,7 +1240,8 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
         if (threadIdx.x < kV2Waves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
         __syncthreads();
         for (uint32_t b = wave; b < nBands; b += kV2Waves)
-            fill2d_band<CH, WAVES>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, check, crtest, bad);
+            if (check) fill2d_band<CH, WAVES, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad);
+            else fill2d_band<CH, WAVES, false>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad);
         if (check) {
             if (!__syncthreads_or(bad)) return;  // converged (:1355-1359), before the border pass
         } else {

@@ -1667,11 +1667,15 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             const uint64_t dd17 = (((uint64_t)ddwN << 32) | ddw) >> sh0, du17 = (((uint64_t)duwN << 32) | duw) >> sh0;
             const uint32_t h16 = hw >> sh0;
             uint32_t newBits = 0;
+            // the windows as two 32-bit halves: bit tests at compile-time positions stay 32-bit operations
+            const uint32_t dLo = (uint32_t)d17, dHi = (uint32_t)(d17 >> 32), uLo = (uint32_t)u17, uHi = (uint32_t)(u17 >> 32);
+            const uint32_t ddLo = (uint32_t)dd17, ddHi = (uint32_t)(dd17 >> 32), duLo = (uint32_t)du17, duHi = (uint32_t)(du17 >> 32);
+            auto bit = [](uint32_t lo, uint32_t hi, int i) -> bool { return i < 32 ? ((lo >> i) & 1u) != 0 : ((hi >> (i - 32)) & 1u) != 0; };
 #pragma unroll
             for (int k = 0; k < kCreepCh; ++k) {
-                const bool cD = (d17 >> k) & 1u, cU = (u17 >> k) & 1u, cH = (h16 >> k) & 1u;
-                const float wr = ((d17 >> (k + 1)) & 1u) ? swf : (((u17 >> (k + 1)) & 1u) ? 1.f : 0.f);
-                float wd = ((dd17 >> (k + 1)) & 1u) ? swf : (((du17 >> (k + 1)) & 1u) ? 1.f : 0.f);
+                const bool cD = bit(dLo, dHi, k), cU = bit(uLo, uHi, k), cH = (h16 >> k) & 1u;
+                const float wr = bit(dLo, dHi, k + 1) ? swf : (bit(uLo, uHi, k + 1) ? 1.f : 0.f);
+                float wd = bit(ddLo, ddHi, k + 1) ? swf : (bit(duLo, duHi, k + 1) ? 1.f : 0.f);
                 const float right = (k < kCreepCh - 1) ? rc[k + 1] : ringRow[rNext];
                 float down = (k < kCreepCh - 1) ? rb[k + 1] : ringBelow[rNext];
                 const float center = prevRight;

@@ -1887,7 +1887,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         launch_fill_prologue(false, d_field, stats.get(), nx, ny, nz, maskS.get(), mws, mbRows.get(), mbCols.get(), true, false, 0.f, relaxCrit, stream);
         // small batches and short calls: 16 waves x 16 columns; from FILL_WIDE_NZ slices on: 8 waves x 32 columns
         const int geometry = tuning("FILL_GEOMETRY", 0);  // 0: by batch size, 1: 16 x 16, 2: 8 x 32
-        const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 48));
+        const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 8));
         auto launch = [&](auto kernel, int ch, int waves) {
             const size_t ldsBytes = (size_t)waves * (kWave + 1) * (2 * ch + 1) * sizeof(float) + (size_t)waves * 2 * kHandW * sizeof(float) +
                                     (size_t)waves * 4 * sizeof(unsigned int);

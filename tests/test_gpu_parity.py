@@ -225,7 +225,7 @@ def _oracle_fill2d(nx, ny, nz, z, relaxCrit, corrEff, maxLoop):
 
 
 def test_fill2d_geometry_follows_the_batch_size(fa, monkeypatch):
-    """48 slices and more run the 8-wave, 32-column geometry by default; the result does not depend on it."""
+    """Eight slices and more run the 8-wave, 32-column geometry by default; the result does not depend on it."""
     f = np.stack([cases.holes(1, 90, 140, seed=5)[0]] * 50)
     want, wn, rc = oracle.fill2d(f[0], 4.0, 1.6, 40)
     got, nch = fa.fill2d_host(f, 4.0, 1.6, 40)

@@ -3,13 +3,21 @@
 
 One "step" = one pass of the hot path over one batch of slices: ONE launch of the bilinear apply
 kernel over NZ time x level slices that already sit in HBM (default NZ = 200, the north-star batch;
-the geometry is BASELINE.json configs[1], "C2").  N > 1: one process per GPU, every rank regrids its own
-NZ slices with a replicated plan (weak scaling, no data-path collective -- the reference's MPI mode shards
-time steps the same way, src/NetCDF_CDMWriter.cc:632-646); the RCCL gather of the finished slices to
-rank 0 ("write-back") is timed separately and reported beside the metric.
+the geometry is BASELINE.json configs[1], "C2").  N > 1: one process per GPU with a replicated plan and no
+data-path collective -- the reference's MPI mode shards time steps the same way
+(src/NetCDF_CDMWriter.cc:632-663).
+  --scaling weak (default): every rank regrids its own NZ slices; the RCCL gather of the finished slices to
+      rank 0 ("write-back") is timed separately and reported beside the metric.
+  --scaling strong: the NZ slices are split over the ranks (fimex_amd.sharding.slice_range; BASELINE configs[2]
+      is this with --method bicubic: 25 slices per GPU on 8 GPUs); besides the regrid-only metric the step
+      "regrid in z chunks + write-back of every finished chunk while the next one is regridded" is timed and
+      reported with its exposed gather time.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without WORLD_SIZE: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+After the timed steps slices 0, NZ/2 and NZ-1 of the last launch's output are compared bit for bit with the CPU
+oracle (outside the timed region); a mismatch makes the run fail.
 """
 import argparse
 import json
@@ -29,6 +37,51 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n, argv):
+    """--gpus N without WORLD_SIZE: start N ranks as children (torch.distributed.run) BEFORE this process touches the
+    GPU, relay rank 0's JSON line and the exit status.  Nothing here imports torch.cuda or the product library."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in p.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        log("bench.py: the ranks ended without a result line")
+        rc = 1
+    return rc
+
+
+def verify_slices(torch, oracle_method, px, py, wl, d_in, d_out, first_slice, picks):
+    """Bit-for-bit check of a few slices of the timed launch's output against the CPU oracle (test infrastructure used
+    as the checker only) on the very input slices the launch read.  picks: local slice indices."""
+    import oracle
+    bad = []
+    for k in picks:
+        f = d_in[k].cpu().numpy()[None]
+        want = oracle.interpolate_values(oracle_method, px, py, f, wl.inX, wl.inY, wl.outX, wl.outY, nthreads=8)[0]
+        got = d_out[k].cpu().numpy()
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        if not bool(same.all()):
+            bad.append((int(first_slice + k), int((~same).sum())))
+    return bad
+
+
 def build_plan(fa, torch, wl, method, stream):
     """Plan build on the GPU: target axes -> geographic lon/lat (projection) -> fractional source indices -> compact plan."""
     ax, ay = wl.source_axes_rad()
@@ -45,13 +98,13 @@ def build_plan(fa, torch, wl, method, stream):
     return plan, d_px.cpu().numpy(), d_py.cpu().numpy()
 
 
-def make_slices(torch, base, nz):
-    """slice k = base + 0.01 k, resident in HBM ([nz][inY][inX] f32)."""
+def make_slices(torch, base, nz, first=0):
+    """slice k = base + 0.01 (first + k), resident in HBM ([nz][inY][inX] f32)."""
     d_base = torch.from_numpy(base).cuda()
     d_in = torch.empty((nz,) + base.shape, dtype=torch.float32, device="cuda")
     for k0 in range(0, nz, 16):
         k1 = min(nz, k0 + 16)
-        off = 0.01 * torch.arange(k0, k1, dtype=torch.float32, device="cuda")
+        off = 0.01 * torch.arange(first + k0, first + k1, dtype=torch.float32, device="cuda")
         d_in[k0:k1] = d_base[None] + off[:, None, None]
     return d_in
 
@@ -120,28 +173,42 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nz", type=int, default=200, help="time x level slices per GPU per step")
+    ap.add_argument("--nz", type=int, default=200, help="time x level slices: per GPU per step (weak) or in all (strong)")
     ap.add_argument("--method", default="bilinear", choices=["bilinear", "bicubic", "nearest"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --nz slices on every GPU; strong: --nz slices split over the GPUs (configs[2] with --method bicubic)")
+    ap.add_argument("--chunk", type=int, default=5, help="strong scaling: slices per write-back chunk of the overlapped gather")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the single-slice and gather measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-slice, copy and gather measurements")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of three output slices")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device rehearses the N > 1 path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no rank environment: start the ranks ourselves, before anything in this process touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     from fimex_amd import capi as fa
+    from fimex_amd import sharding
     import workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     if args.one_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); --one-device is the single-GPU rehearsal"
+                         % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -150,11 +217,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group(backend="gloo")
-    if args.gpus != world and rank == 0:
-        log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     fa.load()
     fa.set_device(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
+    comm_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     method = {"bilinear": fa.BILINEAR, "bicubic": fa.BICUBIC, "nearest": fa.NEAREST_NEIGHBOR}[args.method]
     stencil = {"bilinear": 2, "bicubic": 4, "nearest": 1}[args.method]
@@ -164,22 +230,46 @@ def main():
     t_plan = time.perf_counter() - t0
     info = plan.info()
     base = wl.base_field()
-    nz = args.nz
-    d_in = make_slices(torch, base, nz)
-    d_out = torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
+    # slices of this rank: weak = its own nz, strong = its block of the nz slices of the job
+    strong = args.scaling == "strong"
+    nz_total = args.nz if strong else world * args.nz
+    first, last = sharding.slice_range(nz_total, world, rank)
+    nz = last - first
+    if nz == 0:
+        raise SystemExit("bench.py: rank %d holds no slice (%d slices over %d ranks)" % (rank, nz_total, world))
+    out_layer, in_layer = wl.outX * wl.outY, wl.inX * wl.inY
+    d_in = make_slices(torch, base, nz, first)
+    # rank 0 holds the job's whole output in strong mode (the write-back target); its own block is a view of it
+    d_full = torch.empty((nz_total, wl.outY, wl.outX), dtype=torch.float32, device="cuda") if (strong and rank == 0 and dist_on) else None
+    d_out = d_full[first:last] if d_full is not None else torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
 
     def step():
         plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream)
 
     wall, kernel_ms = time_launches(torch, step, args.steps, args.warmup, dist_on)
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=comm_dev)
     if dist_on:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall_max = float(wall_t.item())
-    cells_per_step = nz * wl.outX * wl.outY
+    cells_per_step = nz_total * out_layer  # all ranks together
     ms_per_step = wall_max / args.steps * 1e3
-    value = world * cells_per_step / (wall_max / args.steps) / 1e6
+    value = cells_per_step / (wall_max / args.steps) / 1e6
+
+    # parity of the timed launch itself: three slices of its output against the CPU oracle, bit for bit
+    verified, failed = [], []
+    if not args.no_verify:
+        picks = sorted({0, (nz - 1) // 2, nz - 1})
+        failed = verify_slices(torch, {"bilinear": 1, "bicubic": 2, "nearest": 0}[args.method], px, py, wl, d_in, d_out, first, picks)
+        verified = [first + k for k in picks]
+        flag = torch.tensor([len(failed)], dtype=torch.int64, device=comm_dev)
+        if dist_on:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            log("bench.py: PARITY FAILURE on rank %d: (slice, differing cells) %r" % (rank, failed))
+            if dist_on:
+                dist.destroy_process_group()
+            sys.exit(1)
 
     # roofline of the dominant (only) kernel: algorithmic bytes per launch / average launch duration
     # B_alg = nz*4*(N_src + ox*oy) + B_plan, N_src = source cells in the plan's reduced-domain bounding box
@@ -187,33 +277,41 @@ def main():
     # actually touch is reported beside it (smaller where the target grid is coarser than 2 source cells)
     n_src_touched = workloads.touched_source_cells(px, py, wl.inX, wl.inY, stencil) if rank == 0 else 0
     n_src_bbox = workloads.reduced_domain_cells(px, py, wl.inX, wl.inY) if rank == 0 else 0
-    alg_bytes = nz * 4 * (n_src_bbox + wl.outX * wl.outY) + info["planBytes"]
-    alg_bytes_touched = nz * 4 * (n_src_touched + wl.outX * wl.outY) + info["planBytes"]
+    alg_bytes = nz * 4 * (n_src_bbox + out_layer) + info["planBytes"]
+    alg_bytes_touched = nz * 4 * (n_src_touched + out_layer) + info["planBytes"]
     avg_kernel_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM-side bytes per launch from the PMC passes of scripts/collect_profiles.py (rocprofv3 cannot run inside this
+    # process): used only if the recorded launch is this one (method, slices, tile shape), otherwise null
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("%s_nz%d" % (args.method, nz))
+            rec = json.load(open(tf)).get("%s_nz%d" % (args.method, nz))
+            if isinstance(rec, dict) and rec.get("tile") == [info.get("tileW"), info.get("tileH")]:
+                traffic, traffic_source = rec["bytes"], rec.get("source")
         except Exception:
             traffic = None
 
+    kernel_name = ("staged_apply<%d, ...>" % stencil) if info.get("stagedCells") else args.method + "_apply"
     result = {
         "metric": "Mcells/s regridded (%s, 4000x3000->2000x2000 f32)" % args.method,
         "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1] geometry (4000x3000 0.01-deg lon/lat -> 2000x2000 rotated pole, %s), "
-                        "%d time x level slices per GPU per step resident in HBM (north-star batch)" % (args.method, nz),
-            "slices_per_gpu": nz, "sharding": "slices over GPUs, plan replicated, no data-path collective",
+                        "%d time x level slices %s per step resident in HBM (north-star batch)"
+                        % (args.method, args.nz, "split over the GPUs" if strong else "per GPU"),
+            "slices_per_gpu": nz, "slices_total": nz_total,
+            "sharding": "slices over GPUs, plan replicated, no data-path collective",
             "plan_build_s": t_plan, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
         },
+        "verified_slices": verified,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic,
-            "kernel": ("staged_apply<%d, ...>" % (2 if args.method == "bilinear" else 4)) if info.get("stagedCells") else args.method + "_apply",
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": kernel_name,
             "staged_cells_per_slice": info.get("stagedCells"), "tile": [info.get("tileW"), info.get("tileH")],
             "kernel_ms_avg": avg_kernel_ms, "kernel_ms_min": float(np.min(kernel_ms)),
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -226,32 +324,21 @@ def main():
         # configs[1] proper: one time step, one slice (plan read not amortised over z)
         wall1, k1 = time_launches(torch, lambda: plan.apply_device(d_in.data_ptr(), 1, d_out.data_ptr(), stream),
                                   max(args.steps, 20), args.warmup, False)
-        b1 = 4 * (n_src_bbox + wl.outX * wl.outY) + info["planBytes"]
+        b1 = 4 * (n_src_bbox + out_layer) + info["planBytes"]
         result["single_slice"] = {"workload": "configs[1], nz = 1 (112 MB working set: served from the 256 MB Infinity Cache "
                                               "when repeated, not from HBM)", "kernel_ms_avg": float(np.mean(k1)),
-                                  "Mcells_per_s": wl.outX * wl.outY / (float(np.mean(k1)) * 1e-3) / 1e6,
+                                  "Mcells_per_s": out_layer / (float(np.mean(k1)) * 1e-3) / 1e6,
                                   "achieved_GBps": b1 / (float(np.mean(k1)) * 1e-3) / 1e9}
         # the box's copy ceiling for context: a device-to-device copy of the output's size, read + write bytes
-        flat_in, flat_out = d_in.view(-1)[:d_out.numel()], d_out.view(-1)
+        flat_in, flat_out = d_in.view(-1)[:d_out.numel()], d_out.reshape(-1)
         _, kc = time_launches(torch, lambda: flat_out.copy_(flat_in), 10, 2, False)
         result["roofline"]["copy_kernel_GBps"] = 8 * d_out.numel() / (float(np.mean(kc)) * 1e-3) / 1e9
+        step()  # d_out holds the regrid result again
+        torch.cuda.synchronize()
         if dist_on:
-            # write-back: RCCL gather of every rank's finished slices to rank 0 over xGMI, outside the metric
-            from fimex_amd import sharding
             try:
-                dist.barrier()
-                torch.cuda.synchronize()
-                tg = time.perf_counter()
-                # (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)
-                full = sharding.gather_slices(d_out if args.backend == "nccl" else d_out.cpu(), world * nz, dst=0)
-                torch.cuda.synchronize()
-                dist.barrier()
-                tg = time.perf_counter() - tg
-                result["gather"] = {"seconds": tg, "bytes_per_peer": d_out.numel() * 4,
-                                    "GBps_into_root": (world - 1) * d_out.numel() * 4 / tg / 1e9,
-                                    "note": "point-to-point RCCL sends of every rank's output slices to rank 0 "
-                                            "(fimex_amd/sharding.py); not part of value"}
-                del full
+                result["gather"] = (measure_strong_write_back if strong else measure_weak_write_back)(
+                    torch, dist, sharding, args, plan, stream, d_in, d_out, d_full, nz, nz_total, first, in_layer, out_layer, world, rank)
             except Exception as e:  # the write-back is reported beside the metric; the metric stands without it
                 result["gather"] = {"seconds": None, "error": repr(e)[:300]}
 
@@ -269,6 +356,87 @@ def main():
             dist.destroy_process_group()
         except Exception:
             pass
+
+
+def measure_weak_write_back(torch, dist, sharding, args, plan, stream, d_in, d_out, d_full, nz, nz_total, first, in_layer, out_layer, world, rank):
+    """weak scaling: RCCL gather of every rank's finished slices to rank 0 over xGMI, after the regrid, outside the metric
+    (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)."""
+    dist.barrier()
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    full = sharding.gather_slices(d_out if args.backend == "nccl" else d_out.cpu(), nz_total, dst=0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    tg = time.perf_counter() - tg
+    del full
+    return {"seconds": tg, "bytes_per_peer": d_out.numel() * 4, "GBps_into_root": (world - 1) * d_out.numel() * 4 / tg / 1e9,
+            "note": "point-to-point RCCL sends of every rank's output slices to rank 0 (fimex_amd/sharding.py); not part of value"}
+
+
+def measure_strong_write_back(torch, dist, sharding, args, plan, stream, d_in, d_out, d_full, nz, nz_total, first, in_layer, out_layer, world, rank):
+    """strong scaling: the job as the reference's writer sees it (src/NetCDF_CDMWriter.cc:632-663) -- every rank regrids
+    its block in chunks of --chunk slices and each finished chunk travels to rank 0 while the next one is regridded.
+    Timed: the chunked regrid alone, and chunked regrid + overlapped write-back; the difference is the exposed gather."""
+    nmax = -(-nz_total // world)
+    chunk = max(1, args.chunk)
+    on_device = args.backend == "nccl"
+
+    def regrid_chunk(c0, c1):
+        plan.apply_device(d_in.data_ptr() + 4 * in_layer * c0, c1 - c0, d_out.data_ptr() + 4 * out_layer * c0, stream)
+
+    def chunked(with_write_back):
+        reqs = []
+        for c0 in range(0, nmax, chunk):
+            c1 = min(c0 + chunk, nmax)
+            l1 = min(c1, nz)
+            if l1 > c0:
+                regrid_chunk(c0, l1)
+            if with_write_back:
+                mine = d_out[c0:l1] if l1 > c0 else d_out[0:0]
+                if not on_device:
+                    mine = mine.cpu()
+                reqs += sharding.post_chunk_write_back(mine, d_full if on_device else host_full, nz_total, c0, c1, dst=0)
+        for r in reqs:
+            r.wait()
+        torch.cuda.synchronize()
+
+    host_full = torch.empty((nz_total,) + tuple(d_out.shape[1:]), dtype=torch.float32) if (rank == 0 and not on_device) else None
+
+    def timed(fn, reps):
+        fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device="cuda" if on_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    reps = max(3, min(args.steps, 10))
+    t_regrid = timed(lambda: chunked(False), reps)
+    t_both = timed(lambda: chunked(True), reps)
+    ok = None
+    if rank == 0:  # the gathered job equals what the ranks computed: spot check of the last rank's last slice against rank 0's kernel
+        got = (d_full if on_device else host_full)[nz_total - 1]
+        last_in = make_slices(torch, workloads_base(), 1, nz_total - 1)
+        chk = torch.empty_like(d_out[0:1])
+        plan.apply_device(last_in.data_ptr(), 1, chk.data_ptr(), stream)
+        torch.cuda.synchronize()
+        a, b = got.cpu().numpy(), chk[0].cpu().numpy()
+        ok = bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+    return {"seconds_regrid_chunked": t_regrid, "seconds_regrid_and_write_back": t_both, "seconds_exposed": max(0.0, t_both - t_regrid),
+            "chunk_slices": chunk, "bytes_per_peer": nz * out_layer * 4, "write_back_verified": ok,
+            "Mcells_per_s_with_write_back": nz_total * out_layer / t_both / 1e6,
+            "note": "every finished chunk of --chunk slices is sent to rank 0 (point-to-point, batched per chunk) while the next chunk is "
+                    "regridded; value above is the regrid alone"}
+
+
+def workloads_base():
+    import workloads
+    return workloads.BilinearRotatedPole().base_field()
 
 
 if __name__ == "__main__":

@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device rehearses the N > 1 path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--tuning-build", action="store_true",
+                    help="profiling sweeps only: run libfimex_amd_tuning.so, the build that reads the FIMEX_AMD_<NAME> experiment switches")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -217,6 +219,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group(backend="gloo")
+    if args.tuning_build:
+        fa.use_tuning_build(True)
     fa.load()
     fa.set_device(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
@@ -303,7 +307,7 @@ def main():
             "workload": "BASELINE configs[1] geometry (4000x3000 0.01-deg lon/lat -> 2000x2000 rotated pole, %s), "
                         "%d time x level slices %s per step resident in HBM (north-star batch)"
                         % (args.method, args.nz, "split over the GPUs" if strong else "per GPU"),
-            "slices_per_gpu": nz, "slices_total": nz_total,
+            "slices_per_gpu": nz, "slices_total": nz_total, "library": "libfimex_amd_tuning.so" if args.tuning_build else "libfimex_amd.so",
             "sharding": "slices over GPUs, plan replicated, no data-path collective",
             "plan_build_s": t_plan, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
         },

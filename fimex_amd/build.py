@@ -16,10 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libfimex_amd.so")
+TUNING_LIB = os.path.join(HERE, "libfimex_amd_tuning.so")  # the same sources with -DFIMEX_AMD_TUNING: reads FIMEX_AMD_<NAME> switches
 HOSTLIB = os.path.join(HERE, "libfimex_amd_host.so")
-HOSTCLI = os.path.join(HERE, "host_cli.so")  # an executable; the .so suffix keeps it out of git and lets it travel to the GPU box
+HOSTCLI = os.path.join(HERE, "host_cli")  # executable of the C++ host mirror (listed in .gitignore by name)
 
-DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip", "projection.hip", "coordsearch.hip", "hostpipe.hip"]
+DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "staged2.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip", "projection.hip", "coordsearch.hip", "hostpipe.hip"]
 
 # -ffp-contract=off: the kernels reproduce the reference's IEEE arithmetic operation by operation
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -46,10 +47,10 @@ def _headers():
     return hdrs
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+def _compile(src, force, tuning=False):
+    obj = os.path.join(OBJ, os.path.basename(src) + (".tuning.o" if tuning else ".o"))
     if force or _newer(obj, [src] + _headers()):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + HIPCC_FLAGS + (["-DFIMEX_AMD_TUNING"] if tuning else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -58,25 +59,27 @@ def _compile(src, force):
     return obj
 
 
-def build_device(force=False, jobs=4):
+def build_device(force=False, jobs=4, tuning=False):
+    """libfimex_amd.so, or with tuning=True libfimex_amd_tuning.so (experiment switches read from the environment)."""
     os.makedirs(OBJ, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in DEVICE_SOURCES]
+    lib = TUNING_LIB if tuning else LIB
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or _newer(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
+        objs = list(ex.map(lambda s: _compile(s, force, tuning), srcs))
+    if force or _newer(lib, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + [
             "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 def build_host(force=False):
     """C++ host mirror of the reference classes, linked against the C ABI only."""
     if not os.path.isdir(HOST):
         return None
-    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cc") and f != "host_cli.cc")
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cc") and f not in ("host_cli.cc", "Projection.cc"))
     if not srcs:
         return None
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")] + [
@@ -98,8 +101,19 @@ def build_host(force=False):
     return HOSTLIB
 
 
+def clean():
+    """Removes every built artefact, so that the next build starts from the sources alone."""
+    shutil.rmtree(OBJ, ignore_errors=True)
+    for f in (LIB, TUNING_LIB, HOSTLIB, HOSTCLI, os.path.join(HERE, "host_cli.so")):
+        if os.path.exists(f):
+            os.remove(f)
+
+
 def build_all(force=False, jobs=4):
+    if force:
+        clean()
     lib = build_device(force=force, jobs=jobs)
+    build_device(force=force, jobs=jobs, tuning=True)
     host = build_host(force=force)
     return lib, host
 

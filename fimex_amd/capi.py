@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfimex_amd.so")
+# the same sources built with -DFIMEX_AMD_TUNING: the only build that reads the FIMEX_AMD_<NAME> experiment switches
+TUNING_LIB_PATH = os.path.join(_HERE, "libfimex_amd_tuning.so")
 
 OK, ERROR = 1, -1
 
@@ -110,28 +112,45 @@ SYMBOLS = {
 }
 
 _lib = None
+_libs = {}
 
 
-def load():
-    """Load libfimex_amd.so; raises when it has not been built (python -m fimex_amd.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path):
+    if not os.path.exists(path):
         raise FimexAmdError("%s is missing: build it with `python -m fimex_amd.build` (needs hipcc); "
-                            "there is no CPU fallback" % LIB_PATH)
+                            "there is no CPU fallback" % path)
     try:
         # share the HIP runtime torch has already mapped (same SONAME) when torch is in the process
         import torch  # noqa: F401
     except Exception:
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load():
+    """Load libfimex_amd.so; raises when it has not been built (python -m fimex_amd.build)."""
+    global _lib
+    if _lib is None:
+        use_tuning_build(False)
+    return _lib
+
+
+def use_tuning_build(on=True):
+    """Switch this module to libfimex_amd_tuning.so (scripts/ sweeps, tests that force a fallback kernel through a
+    FIMEX_AMD_<NAME> switch) or back to the product library.  Plans belong to the library that made them: switch before
+    creating them.  Returns the previous setting."""
+    global _lib
+    path = TUNING_LIB_PATH if on else LIB_PATH
+    was = _lib is not None and _lib is _libs.get(TUNING_LIB_PATH)
+    if path not in _libs:
+        _libs[path] = _open(path)
+    _lib = _libs[path]
+    return was
 
 
 def _check(rc):

@@ -13,14 +13,21 @@ thread_local std::string g_lastError;
 
 void set_last_error(const std::string& msg) { g_lastError = msg; }
 
+// Experiment switches.  The product library does not read the environment: every switch has its
+// measured default compiled in.  Only the tuning build (-DFIMEX_AMD_TUNING -> libfimex_amd_tuning.so, loaded by scripts/ and by
+// the parity tests that force a fallback kernel) reads FIMEX_AMD_<NAME>, at every call so that one process can sweep settings.
 int tuning(const char* name, int fallback)
 {
-    // read on every call so that one process can sweep settings (bench/tuning scripts); a getenv per launch is noise
+#ifdef FIMEX_AMD_TUNING
     const std::string key = std::string("FIMEX_AMD_") + name;
     const char* v = std::getenv(key.c_str());
     if (!v || !*v) return fallback;
     const int parsed = std::atoi(v);
     return parsed < 0 ? fallback : parsed;
+#else
+    (void)name;
+    return fallback;
+#endif
 }
 
 namespace {

@@ -120,6 +120,13 @@ void require_current_device(int planDevice);  // *_device calls must run on the 
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
+// diagnostics that make a kernel skip its loads or stores exist in the tuning build only
+#ifdef FIMEX_AMD_TUNING
+constexpr bool kTuningBuild = true;
+#else
+constexpr bool kTuningBuild = false;
+#endif
+
 constexpr int kWave = 64;    // CDNA wavefront
 constexpr int kXcds = 8;     // MI355X accelerator complex dies, one L2 each
 constexpr int kBlock = 256;  // 4 waves, one per SIMD

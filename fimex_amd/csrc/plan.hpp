@@ -45,6 +45,25 @@ struct StagedPlan {
     DeviceArray<uint2> tileHdr;
     DeviceArray<uint32_t> ldsA, ldsB;  // LDS offsets of stencil rows 0|1 (and 2|3 for bicubic), 16 bits each
 };
+
+// Second LDS-staged form (staged2.hip): tiles of one height and varying width (narrower where the source footprint of an
+// output cell is larger, so that every tile fits the same LDS budget), workgroups of 256-1024 threads, and per tile the
+// list of 16-byte source chunks itself instead of row segments.
+struct StagedTile {
+    uint32_t x0, y0, w;     // output columns [x0, x0 + w) of rows [y0, y0 + tileH)
+    uint32_t nChunks;       // 16-byte chunks streamed per slice
+    uint32_t chunkBase;     // first entry in chunkOff
+    uint32_t rsv[3];
+};
+struct Staged2Plan {
+    bool valid = false;
+    uint32_t nt = 0, per = 0, kmax = 0, tileH = 0, tileWMax = 0, nTiles = 0, gridX = 0, ldsBytes = 0;
+    size_t stagedCells = 0, totalChunks = 0;
+    DeviceArray<StagedTile> tiles;
+    DeviceArray<uint32_t> order;     // workgroup -> tile, ~0u = none (tile rows dealt to the XCDs in stripes)
+    DeviceArray<uint32_t> chunkOff;  // source cell offset of every chunk inside a slice
+    DeviceArray<uint32_t> ldsA, ldsB;
+};
 }  // namespace fimex_amd
 
 struct fimex_amd_regrid_plan {
@@ -58,6 +77,7 @@ struct fimex_amd_regrid_plan {
     fimex_amd::DeviceArray<float> xf, yf;
     fimex_amd::DeviceArray<double> xfd, yfd;
     fimex_amd::StagedPlan staged;
+    fimex_amd::Staged2Plan staged2;
 
     // forward plans
     fimex_amd::Aggregate aggregate = fimex_amd::Aggregate::Sum;
@@ -85,6 +105,10 @@ bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const do
 void launch_staged_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 bool launch_staged_apply_typed(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
                                hipStream_t stream);
+
+// staged2.hip
+bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
+void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 
 // forward.hip
 void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);

@@ -584,6 +584,20 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
         plan.info.tileW = s.tileW;
         plan.info.tileH = s.tileH;
     }
+    // the second staged form (staged2.hip) serves float slices; the first one stays for 1- and 2-byte stored types
+    // (bicubic keeps the first form where it exists -- 32 x 16 tiles at four workgroups per CU suit its arithmetic -- and takes
+    // the second one for the source widths the first cannot stage, inX % 4 != 0)
+    const int second = tuning("STAGED2", 1);
+    const bool wantSecond = second >= 2 || (second == 1 && (plan.kind != PlanKind::Bicubic || !plan.staged.valid));
+    if (tuning("STAGED", 1) != 0 && wantSecond && build_staged2_plan(plan, d_px, d_py, stream)) {
+        const auto& s = plan.staged2;
+        const size_t perCell = plan.kind == PlanKind::Nearest ? 0 : (plan.kind == PlanKind::Bilinear ? plan.xf.bytes() + plan.yf.bytes()
+                                                                                                       : plan.xfd.bytes() + plan.yfd.bytes());
+        plan.info.planBytes = perCell + s.ldsA.bytes() + s.ldsB.bytes() + s.totalChunks * 4 + (size_t)s.nTiles * sizeof(StagedTile) + s.order.bytes();
+        plan.info.stagedCells = s.stagedCells;
+        plan.info.tileW = s.tileWMax;
+        plan.info.tileH = s.tileH;
+    }
 }
 
 void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
@@ -591,6 +605,10 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
     if (nz == 0) return;
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
     // the staged kernel pays a per-tile set-up (row table, chunk list) that only amortises over a few slices
+    if (plan.staged2.valid && tuning("STAGED", 1) != 0 && tuning("STAGED2", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
+        launch_staged2_apply(plan, d_in, nz, d_out, stream);
+        return;
+    }
     if (plan.staged.valid && tuning("STAGED", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
         launch_staged_apply(plan, d_in, nz, d_out, stream);
         return;

@@ -18,6 +18,7 @@
 // 2-4 slices of prefetch depth (equal), non-temporal loads (-15 %), plain stores (-6 %), XCD-contiguous or striped
 // tile orders (equal or worse than plain round-robin).
 #include "plan.hpp"
+#include "staged_common.hpp"
 #include "typed_convert.hpp"
 
 #include <type_traits>
@@ -26,68 +27,12 @@ namespace fimex_amd {
 
 namespace {
 
-__device__ __forceinline__ float undefined_f() { return __uint_as_float(0x7fc00000u); }
-
-__device__ __forceinline__ bool usable(double x, double y)
-{
-    const double lim = 1073741824.0;
-    return (fabs(x) < lim) && (fabs(y) < lim);
-}
-
-constexpr int kMaxRows = 160;  // source rows one tile may span
-
 struct TileGeom {
     uint32_t outX, outY;
     uint32_t tileW, tileH;  // output cells per tile (tileW * tileH = 256 * outputs per lane)
     uint32_t tilesX, nTiles;
     uint32_t capChunks;     // 16-byte chunks one LDS buffer holds
 };
-
-// which source cells one output cell reads: columns xa..xb of rows ya..yb (inclusive)
-struct CellNeed {
-    bool valid;
-    int64_t xa, xb, ya, yb;
-};
-
-// STENCIL 1: nearest (src/interpolation.c:862-879); 2: bilinear incl. its border branches (:883-954); 4: bicubic (:970-976)
-template <int STENCIL>
-__device__ CellNeed classify(double x, double y, int64_t ix, int64_t iy)
-{
-    CellNeed c{};
-    c.valid = false;
-    if (!usable(x, y)) return c;
-    if (STENCIL == 1) {  // nearest: lround half away from zero (src/interpolation.c:864-868)
-        const int64_t rx = (int64_t)round(x), ry = (int64_t)round(y);
-        if (rx >= 0 && rx < ix && ry >= 0 && ry < iy) { c.valid = true; c.xa = c.xb = rx; c.ya = c.yb = ry; }
-        return c;
-    }
-    const int64_t x0 = (int64_t)floor(x), y0 = (int64_t)floor(y);
-    if (STENCIL == 4) {
-        if ((1 <= x0) && (x0 + 2 < ix) && (1 <= y0) && (y0 + 2 < iy)) {
-            c.valid = true; c.xa = x0 - 1; c.xb = x0 + 2; c.ya = y0 - 1; c.yb = y0 + 2;
-        }
-        return c;
-    }
-    const bool xlin = (0 <= x0) && (x0 + 1 < ix);
-    const bool ylin = (0 <= y0) && (y0 + 1 < iy);
-    if (xlin && ylin) {
-        c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = y0; c.yb = y0 + 1;
-    } else if (xlin) {
-        const int64_t ry = (int64_t)round(y);
-        if (0 <= ry && ry < iy) { c.valid = true; c.xa = x0; c.xb = x0 + 1; c.ya = c.yb = ry; }
-    } else {
-        const int64_t rx = (int64_t)round(x);
-        if (0 <= rx && rx < ix) {
-            if (ylin) {
-                c.valid = true; c.xa = c.xb = rx; c.ya = y0; c.yb = y0 + 1;
-            } else {
-                const int64_t ry = (int64_t)round(y);
-                if (0 <= ry && ry < iy) { c.valid = true; c.xa = c.xb = rx; c.ya = c.yb = ry; }
-            }
-        }
-    }
-    return c;
-}
 
 struct BuildCounters {
     unsigned long long overflow, stagedChunks;
@@ -213,32 +158,8 @@ struct StagedArgs {
     uint32_t nOut;
     uint32_t nz, zPerBlock;
     uint32_t tilesPerXcd, xcdRemap, storeAux, loadAux;
-    uint32_t ablate;  // diagnostics only (FIMEX_AMD_ABLATE): 1 = no source loads, 2 = no output stores
+    uint32_t ablate;  // tuning build only (FIMEX_AMD_ABLATE): 1 = no source loads, 2 = no output stores
 };
-
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-
-// One LDS-DMA wave instruction: 64 lanes x 16 bytes from per-lane buffer offsets to ldsBase + lane * 16.
-// (The builtin exists only in the device pass; the host pass of hipcc parses kernel bodies too.)
-__device__ __forceinline__ void dma16(rsrc_t rs, float* ldsBase, uint32_t voff, uint32_t aux = 0)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    using lds_ptr = __attribute__((address_space(3))) void*;
-    switch (aux) {  // cache policy, wave-uniform (tuning knob LOAD_AUX; the default policy measured best)
-    case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 1); break;
-    case 16: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 16); break;
-    case 17: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 17); break;
-    case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 2); break;
-    default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)ldsBase, 16, voff, 0, 0, 0); break;
-    }
-#else
-    (void)rs; (void)ldsBase; (void)voff; (void)aux;
-#endif
-}
 
 // The same with 4 bytes per lane (256 bytes per wave instruction): sources of 1- and 2-byte elements, whose row segments
 // start on 4-byte but not on 16-byte boundaries.
@@ -286,35 +207,6 @@ __device__ __forceinline__ void store_result(rsrc_t ro, uint32_t cellByteOff, fl
         else if constexpr (sizeof(T) == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, ro, cellByteOff / 2, 0, 2);
         else __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, ro, cellByteOff, 0, 2);
     }
-}
-
-// Keys kernel a = -0.5: rows of M/2 (src/interpolation.c:962-968), weights XM / MY (:977-1000)
-__device__ __forceinline__ void cubic_weights(double f, double w[4])
-{
-    const double M[4][4] = {{0.0, 1.0, 0.0, 0.0}, {-0.5, 0.0, 0.5, 0.0}, {1.0, -2.5, 2.0, -0.5}, {-0.5, 1.5, -1.5, 0.5}};
-    double X[4];
-    X[0] = 1;
-    X[1] = f;
-    X[2] = f * f;
-    X[3] = X[2] * f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        double s = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += X[j] * M[j][i];
-        w[i] = s;
-    }
-}
-
-// STENCIL: 2 bilinear, 4 bicubic; PER: outputs per lane; KMAX: 16-byte chunks per lane and slice
-// (KMAX * 256 * 16 bytes = one LDS buffer).
-// s_waitcnt on vmcnt only (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
-template <int N>
-__device__ __forceinline__ void wait_vmcnt()
-{
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
-    asm volatile("" ::: "memory");
 }
 
 // NBUF: LDS buffers of the slice ring; NBUF - 1 slices are in flight while one is interpolated.  What a workgroup waits
@@ -470,7 +362,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     // one wave instruction moves 64 pieces (1 KiB or 256 bytes): LDS destination = wave-uniform base + lane * piece size
     const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
     auto dma = [&](float* dst, uint32_t z) {
-        const rsrc_t rs = make_rsrc(inBase + (size_t)z * inBytes, (a.ablate & 1) ? 0u : inBytes);
+        const rsrc_t rs = make_rsrc(inBase + (size_t)z * inBytes, (kTuningBuild && (a.ablate & 1)) ? 0u : inBytes);
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             if constexpr (EB == 4 || kWide) dma16(rs, dst + (waveChunk + j * kBlock) * 4, gOff[j], a.loadAux);
@@ -497,7 +389,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
             dma(smem + ((slot + NBUF - 1) % NBUF) * kBufFloats, z + (NBUF - 1));  // into the buffer slice z - 1 has left
         }
         const float* cur = smem + slot * kBufFloats;
-        const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, (a.ablate & 2) ? 0u : outBytes);
+        const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, (kTuningBuild && (a.ablate & 2)) ? 0u : outBytes);
         const char* curb = reinterpret_cast<const char*>(cur);
         if constexpr (STENCIL == 1) {
             float v[PER];

@@ -1,0 +1,541 @@
+// LDS-staged backward regrid, second form: the bandwidth path of the headline metric from round 2 on.
+//
+// Same arithmetic as staged.hip / regrid.hip (src/interpolation.c:862-1028) and the same idea -- a workgroup owns a tile of
+// OUTPUT cells, streams the source row segments that tile needs HBM -> LDS by LDS-DMA for slice z + d while slice z is
+// interpolated out of LDS -- with the structure that the access calibration of round 2 asks for
+// (scripts/calib/stream_pattern.hip, profiles/calib/r02_stream_pattern_*.jsonl):
+//   * workgroups of 256, 512 or 1024 threads on tiles 2-4 times as large: the lines at the ends of a row segment and the
+//     halo rows are shared with the neighbouring tile, and only tiles that run in lockstep share them for certain;
+//   * tiles of one height and VARYING width: an output cell of the benchmark plan covers 1.6 .. 3.3 source columns, so a
+//     uniform tile grid sizes every LDS slot for the worst tile and leaves 40 % of it unused.  Here the plan narrows the
+//     tiles of a tile row until every tile fits the same budget;
+//   * a slice ring whose depth each workgroup derives from its own tile (LDS bytes / slot bytes of this tile, 2 .. maxDepth)
+//     instead of one compile-time depth sized for the largest tile;
+//   * the plan stores the source offset of every 16-byte chunk of a tile, so the workgroup prologue is a coalesced load
+//     instead of a binary search per chunk, and row segments start on 16-byte boundaries of the slice for any row length
+//     (inX % 4 != 0 included: a reduced domain, src/CachedInterpolation.cc:159-200, crops to arbitrary widths);
+//   * DMA instructions whose 64 chunks all lie beyond the tile's list are not issued (the wait counts follow at run time);
+//   * tile rows are dealt to the XCDs in stripes (neighbours in x share an L2) through a workgroup -> tile table.
+#include "plan.hpp"
+#include "staged_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace fimex_amd {
+
+namespace {
+
+// One workgroup per tile.  emit == 0: counts the 16-byte chunks of the tile's row segments (tiles[t].nChunks, ~0u = does not
+// fit).  emit == 1: writes the chunk list and every output cell's LDS offsets (16 bits per stencil row, in floats).
+template <int STENCIL>
+__global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ px, const double* __restrict__ py, int64_t ix, int64_t iy,
+                                                    uint32_t outX, uint32_t outY, uint32_t tileH, StagedTile* __restrict__ tiles,
+                                                    uint32_t capChunks, int emit, uint32_t* __restrict__ chunkOff,
+                                                    uint32_t* __restrict__ ldsA, uint32_t* __restrict__ ldsB)
+{
+    __shared__ int shRmin, shRmax, shFail;
+    __shared__ int rowMin[kMaxRows], rowMax[kMaxRows];
+    __shared__ uint32_t rowChunk[kMaxRows + 1];
+    const uint32_t t = blockIdx.x;
+    const StagedTile T = tiles[t];
+    const uint32_t nCells = T.w * tileH;
+    if (threadIdx.x == 0) { shRmin = 0x7FFFFFFF; shRmax = -1; shFail = 0; }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nCells; e += kBlock) {
+        const uint32_t y = T.y0 + e / T.w, x = T.x0 + e % T.w;
+        if (y >= outY) continue;
+        const size_t cell = (size_t)y * outX + x;
+        const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+        if (c.valid) { atomicMin(&shRmin, (int)c.ya); atomicMax(&shRmax, (int)c.yb); }
+    }
+    __syncthreads();
+    const int rmin = shRmin;
+    const int nr = (shRmax >= rmin) ? shRmax - rmin + 1 : 0;
+    if (nr > kMaxRows) {
+        if (threadIdx.x == 0 && !emit) tiles[t].nChunks = 0xFFFFFFFFu;
+        return;
+    }
+    for (int i = threadIdx.x; i < nr; i += kBlock) { rowMin[i] = 0x7FFFFFFF; rowMax[i] = -0x7FFFFFFF; }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nCells; e += kBlock) {
+        const uint32_t y = T.y0 + e / T.w, x = T.x0 + e % T.w;
+        if (y >= outY) continue;
+        const size_t cell = (size_t)y * outX + x;
+        const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+        if (c.valid)
+            for (int64_t r = c.ya; r <= c.yb; ++r) {
+                atomicMin(&rowMin[r - rmin], (int)c.xa);
+                atomicMax(&rowMax[r - rmin], (int)c.xb);
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t layer = ix * iy;
+        uint32_t acc = 0;
+        for (int i = 0; i < nr; ++i) {
+            rowChunk[i] = acc;
+            if (rowMax[i] >= rowMin[i]) {
+                // the segment starts on a 16-byte boundary of the SLICE (the DMA moves 16 bytes per lane; aligned pieces stay
+                // inside one line): it may begin up to 3 cells before the first cell needed, in the row above for x < 0
+                const int64_t first = (int64_t)(rmin + i) * ix + rowMin[i];
+                int64_t start = first & ~(int64_t)3;
+                const uint32_t nch = (uint32_t)((first - start + (rowMax[i] - rowMin[i])) / 4 + 1);
+                // a last chunk that would cross the end of the slice is moved back instead (unaligned, still whole)
+                if (start + 4 * (int64_t)nch > layer) start = layer - 4 * (int64_t)nch;
+                if (start < 0) shFail = 1;
+                rowMin[i] = (int)(start - (int64_t)(rmin + i) * ix);  // column of the segment's first cell, may be negative
+                acc += nch;
+            }
+        }
+        rowChunk[nr] = acc;
+        if (acc > capChunks) shFail = 1;
+    }
+    __syncthreads();
+    if (!emit) {
+        if (threadIdx.x == 0) tiles[t].nChunks = shFail ? 0xFFFFFFFFu : rowChunk[nr];
+        return;
+    }
+    const uint32_t total = rowChunk[nr];
+    for (uint32_t c = threadIdx.x; c < total; c += kBlock) {
+        uint32_t lo = 0, hi = (uint32_t)nr - 1;  // last row whose first chunk <= c and that holds chunks
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (rowChunk[mid] <= c) lo = mid; else hi = mid - 1;
+        }
+        chunkOff[T.chunkBase + c] = (uint32_t)((int64_t)(rmin + (int)lo) * ix + rowMin[lo] + 4 * (int64_t)(c - rowChunk[lo]));
+    }
+    for (uint32_t e = threadIdx.x; e < nCells; e += kBlock) {
+        const uint32_t y = T.y0 + e / T.w, x = T.x0 + e % T.w;
+        if (y >= outY) continue;
+        const size_t cell = (size_t)y * outX + x;
+        const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+        uint32_t a = kInvalidPos, b = kInvalidPos;
+        if (c.valid) {
+            uint32_t off[4];
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = (c.ya + r <= c.yb) ? c.ya + r : c.yb;  // missing rows repeat the last one
+                const int i = (int)(row - rmin);
+                off[r] = rowChunk[i] * 4 + (uint32_t)(c.xa - rowMin[i]);
+            }
+            a = off[0] | (off[1] << 16);
+            b = off[2] | (off[3] << 16);
+        }
+        ldsA[cell] = a;
+        if (STENCIL == 4) ldsB[cell] = b;
+    }
+}
+
+constexpr int kMaxZChunks = 31;
+
+struct Staged2Args {
+    const float* in;
+    float* out;
+    const StagedTile* tiles;
+    const uint32_t* order;
+    const uint32_t* chunkOff;
+    const uint32_t* ldsA;
+    const uint32_t* ldsB;
+    const float* xf;
+    const float* yf;
+    const double* xfd;
+    const double* yfd;
+    uint32_t outX, outY, tileH;
+    uint32_t inBytes;    // one source slice
+    uint32_t nOut;
+    uint32_t nz;
+    uint32_t zStart[kMaxZChunks + 1];  // slices [zStart[c], zStart[c + 1]) belong to z chunk c = blockIdx.y
+    uint32_t ldsFloats;  // floats of the slice ring
+    uint32_t maxDepth;
+    uint32_t flags;      // tuning build only: 1 no source loads, 2 no result stores
+};
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): a jump over the 64 encodings
+__device__ __forceinline__ void wait_vmcnt_dyn(uint32_t n)
+{
+    n = __builtin_amdgcn_readfirstlane(n);
+#define FA_W(k) case k: wait_vmcnt<k>(); break;
+#define FA_W8(k) FA_W(k) FA_W(k + 1) FA_W(k + 2) FA_W(k + 3) FA_W(k + 4) FA_W(k + 5) FA_W(k + 6) FA_W(k + 7)
+    switch (n) {
+        FA_W8(0) FA_W8(8) FA_W8(16) FA_W8(24) FA_W8(32) FA_W8(40) FA_W8(48)
+        FA_W(56) FA_W(57) FA_W(58) FA_W(59) FA_W(60) FA_W(61) FA_W(62)
+    default: wait_vmcnt<63>(); break;
+    }
+#undef FA_W8
+#undef FA_W
+}
+
+// STENCIL: 1 nearest, 2 bilinear, 4 bicubic; NT: threads of the workgroup; PER: outputs per lane (tile = NT * PER outputs);
+// KMAX: most 16-byte chunks a lane stages per slice.
+template <int STENCIL, int NT, int PER, int KMAX>
+__global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const uint32_t tile = a.order[blockIdx.x];
+    if (tile == 0xFFFFFFFFu) return;
+    const StagedTile T = a.tiles[tile];
+    const uint32_t z0 = a.zStart[blockIdx.y];
+    const uint32_t z1 = a.zStart[blockIdx.y + 1];
+    const uint32_t nzl = z1 - z0;
+
+    const uint32_t outBytes = a.nOut * 4u;
+    const char* inBase = reinterpret_cast<const char*>(a.in);
+    char* outBase = reinterpret_cast<char*>(a.out);
+    const uint32_t outRecords = (kTuningBuild && (a.flags & 2)) ? 0u : outBytes;
+
+    // ---- the staging list and the first DMAs come before everything else: the per-output plan below loads while they fly
+    // per-lane staging list: chunk c = threadIdx.x + j * NT of the tile's list; a wave skips the instructions whose 64
+    // chunks all lie beyond the list (un = instructions this wave issues per slice)
+    const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
+    uint32_t gOff[KMAX];
+    uint32_t un = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const uint32_t c = threadIdx.x + j * NT;
+        gOff[j] = (c < T.nChunks) ? a.chunkOff[T.chunkBase + c] * 4u : 0xFFFFFFFFu;  // ~0u: dropped by the bounds check (zeros)
+        if (waveChunk + j * NT < T.nChunks) un = j + 1;
+    }
+    un = __builtin_amdgcn_readfirstlane(un);
+    const uint32_t slotFloats = ((T.nChunks + 63u) & ~63u) * 4u + 4u;
+    uint32_t depth = a.ldsFloats / slotFloats;  // >= 2 by construction of the plan
+    depth = min(depth, a.maxDepth);
+    depth = min(depth, nzl + 1);
+    if (depth < 2) depth = 2;
+    const uint32_t inRecords = (kTuningBuild && (a.flags & 1)) ? 0u : a.inBytes;
+
+    auto dma = [&](uint32_t slot, uint32_t z) {
+        const rsrc_t rs = make_rsrc(inBase + (size_t)z * a.inBytes, inRecords);
+        float* dst = smem + slot * slotFloats;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if ((uint32_t)j < un) dma16(rs, dst + (waveChunk + j * NT) * 4, gOff[j]);
+    };
+
+    // prologue: depth - 1 slices in flight, the first one landed
+    const uint32_t pre = min(depth - 1, nzl);
+    for (uint32_t i = 0; i < pre; ++i) dma(i, z0 + i);
+    // ---- per-lane plan: outputs e = threadIdx.x + k * NT of the tile (a wave covers 64 consecutive cells of one row)
+    uint32_t cellOff[PER];
+    uint32_t row[PER][STENCIL];
+    float xf[PER], yf[PER];
+    double XM[PER][4], MY[PER][4];
+    bool undef[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t e = threadIdx.x + k * NT;
+        const uint32_t ly = e / T.w, lx = e - ly * T.w;
+        const uint32_t y = T.y0 + ly;
+        cellOff[k] = 0xFFFFFFFFu;
+        uint32_t pa = kInvalidPos, pb = kInvalidPos;
+        xf[k] = yf[k] = 0.f;
+        double fx = 0, fy = 0;
+        if (ly < a.tileH && y < a.outY) {
+            const uint32_t cell = y * a.outX + T.x0 + lx;
+            cellOff[k] = cell * 4u;
+            pa = a.ldsA[cell];
+            if (STENCIL == 4) { pb = a.ldsB[cell]; fx = a.xfd[cell]; fy = a.yfd[cell]; }
+            else if (STENCIL == 2) { xf[k] = a.xf[cell]; yf[k] = a.yf[cell]; }
+        }
+        undef[k] = pa == kInvalidPos;  // undefined cells read LDS offset 0 and discard it
+        row[k][0] = undef[k] ? 0u : (pa & 0xFFFFu) * 4u;
+        if (STENCIL >= 2) row[k][STENCIL >= 2 ? 1 : 0] = undef[k] ? 0u : (pa >> 16) * 4u;
+        if (STENCIL == 4) {
+            row[k][2] = undef[k] ? 0u : (pb & 0xFFFFu) * 4u;
+            row[k][3] = undef[k] ? 0u : (pb >> 16) * 4u;
+            cubic_weights(fx, XM[k]);
+            cubic_weights(fy, MY[k]);
+        }
+    }
+    if (T.nChunks == 0) {  // nothing of the source is needed: every output of the tile is undefined
+        for (uint32_t z = z0; z < z1; ++z) {
+            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) __builtin_amdgcn_raw_buffer_store_b32(0x7fc00000u, ro, cellOff[k], 0, 2);
+        }
+        return;
+    }
+
+    wait_vmcnt_dyn((pre - 1) * un);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint32_t slot = 0;
+    for (uint32_t i = 0; i < nzl; ++i) {
+        const uint32_t z = z0 + i;
+        if (i + depth - 1 < nzl) {  // into the slot slice i - 1 has left
+            uint32_t s = slot + depth - 1;
+            if (s >= depth) s -= depth;
+            dma(s, z + depth - 1);
+        }
+        const char* curb = reinterpret_cast<const char*>(smem + slot * slotFloats);
+        const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+        if constexpr (STENCIL == 1) {
+            float v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
+#pragma unroll
+            for (int k = 0; k < PER; ++k)  // src/interpolation.c:869-876
+                __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);
+        } else if constexpr (STENCIL == 2) {
+            float s00[PER], s01[PER], s10[PER], s11[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {  // all stencil reads first: 2 x ds_read2_b32 per output, no waits in between
+                const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
+                const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
+                s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
+                // interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911)
+                const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];
+                const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];
+                const float inter = (1.f - yf[k]) * top + yf[k] * bot;
+                const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
+                float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
+                r = undef[k] ? undefined_f() : r;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                float f[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[r][j] = *reinterpret_cast<const float*>(curb + row[k][r] + 4 * j);
+                }
+                float acc = 0;  // interpolation.c:1005: accumulates into the float output
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double xmf = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[r][j];  // :1015
+                    acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(undef[k] ? undefined_f() : acc), ro, cellOff[k], 0, 2);
+            }
+        }
+        if (i + 1 < nzl) {
+            // Slice i + 1 must have landed.  Results come back in issue order; issued after its DMA and allowed to stay in
+            // flight: the DMAs of the slices behind it and the stores of the iterations since.
+            const uint32_t lastIssued = min(i + depth - 1, nzl - 1);
+            const uint32_t youngerDma = lastIssued - (i + 1);
+            const uint32_t youngerStores = min(depth - 1, i + 1);
+            wait_vmcnt_dyn(min(63u, youngerDma * un + youngerStores * PER));
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = (slot + 1 == depth) ? 0 : slot + 1;
+    }
+}
+
+struct Shape2 {
+    int nt, per, kmax;
+    uint32_t tileW, tileH;  // widest tile
+    uint32_t ldsBytes;
+};
+
+template <int STENCIL, int NT, int PER, int KMAX>
+void launch_one(const Staged2Args& a, dim3 grid, size_t ldsBytes, hipStream_t stream)
+{
+    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply2<STENCIL, NT, PER, KMAX>), ldsBytes);
+    staged_apply2<STENCIL, NT, PER, KMAX><<<grid, NT, ldsBytes, stream>>>(a);
+}
+
+template <int STENCIL>
+void launch_shape(const Staged2Plan& s, const Staged2Args& a, dim3 grid, hipStream_t stream)
+{
+    const uint32_t key = s.nt * 10000 + s.per * 100 + s.kmax;
+    switch (key) {
+    case 2560406: launch_one<STENCIL, 256, 4, 6>(a, grid, s.ldsBytes, stream); break;
+    case 5120406: launch_one<STENCIL, 512, 4, 6>(a, grid, s.ldsBytes, stream); break;
+    case 10240405: launch_one<STENCIL, 1024, 4, 5>(a, grid, s.ldsBytes, stream); break;
+    case 5120203: launch_one<STENCIL, 512, 2, 3>(a, grid, s.ldsBytes, stream); break;
+    case 10240203: launch_one<STENCIL, 1024, 2, 3>(a, grid, s.ldsBytes, stream); break;
+    case 2560204: launch_one<STENCIL, 256, 2, 4>(a, grid, s.ldsBytes, stream); break;
+    default: throw Error("staged2: unexpected workgroup shape");
+    }
+}
+
+template <int STENCIL>
+bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream, const Shape2& sh, uint32_t stripe)
+{
+    const uint32_t outX = (uint32_t)plan.outX, outY = (uint32_t)plan.outY;
+    const uint32_t tileH = sh.tileH;
+    const uint32_t nBands = (uint32_t)ceil_div(outY, tileH);
+    // the ring holds at least two slots of the largest tile; a slot is its chunks rounded up to whole wave instructions
+    uint32_t cap = (sh.ldsBytes / 2 - 16) / 16;
+    cap = std::min<uint32_t>(cap & ~63u, (uint32_t)sh.kmax * sh.nt);
+    cap = std::min<uint32_t>(cap, 16383u);  // 16-bit LDS offsets in floats
+    const uint32_t step = sh.tileW >= 128 ? 64u : 32u;  // tile widths are multiples of this (a wave stores 64 consecutive cells)
+    std::vector<uint32_t> bandW(nBands, std::min(sh.tileW, (outX + step - 1) / step * step));
+    std::vector<StagedTile> tiles;
+    std::vector<uint32_t> bandOf;
+    DeviceArray<StagedTile> dTiles;
+    for (int pass = 0;; ++pass) {
+        tiles.clear();
+        bandOf.clear();
+        for (uint32_t b = 0; b < nBands; ++b)
+            for (uint32_t x0 = 0; x0 < outX; x0 += bandW[b]) {
+                StagedTile t{};
+                t.x0 = x0;
+                t.y0 = b * tileH;
+                t.w = std::min(bandW[b], outX - x0);
+                tiles.push_back(t);
+                bandOf.push_back(b);
+            }
+        if (tiles.size() > 0x7FFFFFFFu / 8) return false;
+        dTiles.allocate(tiles.size());
+        FA_HIP(hipMemcpyAsync(dTiles.get(), tiles.data(), tiles.size() * sizeof(StagedTile), hipMemcpyHostToDevice, stream));
+        tile_scan<STENCIL><<<(uint32_t)tiles.size(), kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, outX, outY, tileH,
+                                                                       dTiles.get(), cap, 0, nullptr, nullptr, nullptr);
+        FA_HIP(hipGetLastError());
+        FA_HIP(hipMemcpyAsync(tiles.data(), dTiles.get(), tiles.size() * sizeof(StagedTile), hipMemcpyDeviceToHost, stream));
+        FA_HIP(hipStreamSynchronize(stream));
+        // tile rows with a tile that does not fit (too many chunks for the slot, too many source rows) are narrowed and
+        // scanned again
+        std::vector<char> narrowed(nBands, 0);
+        bool again = false;
+        for (size_t i = 0; i < tiles.size(); ++i)
+            if (tiles[i].nChunks == 0xFFFFFFFFu && !narrowed[bandOf[i]]) {
+                uint32_t& w = bandW[bandOf[i]];
+                if (w <= step) return false;  // not even the narrowest tile fits: positions without spatial coherence
+                w -= step;
+                narrowed[bandOf[i]] = 1;
+                again = true;
+            }
+        if (!again) break;
+        if (pass > 64) return false;
+    }
+    size_t total = 0;
+    for (auto& t : tiles) {
+        FA_REQUIRE(total <= 0xFFFFFFFFu, "staged plan: too many chunks");
+        t.chunkBase = (uint32_t)total;
+        total += t.nChunks;
+    }
+    if (total > 0xFFFFFFFFull) return false;
+    FA_HIP(hipMemcpyAsync(dTiles.get(), tiles.data(), tiles.size() * sizeof(StagedTile), hipMemcpyHostToDevice, stream));
+    const size_t n = plan.outX * plan.outY;
+    Staged2Plan& s = plan.staged2;
+    s.chunkOff.allocate(std::max<size_t>(total, 1));
+    s.ldsA.allocate(n);
+    s.ldsB.allocate(STENCIL == 4 ? n : 0);
+    tile_scan<STENCIL><<<(uint32_t)tiles.size(), kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, outX, outY, tileH,
+                                                                   dTiles.get(), cap, 1, s.chunkOff.get(), s.ldsA.get(), s.ldsB.get());
+    FA_HIP(hipGetLastError());
+    // workgroup -> tile: workgroups are dealt round-robin over the XCDs (b % 8 shares an L2); tile rows go to the XCDs in
+    // stripes of `stripe` rows, so that neighbours in x (and, inside a stripe, in y) run on the same XCD and meet in its L2
+    // (stripes of about `stripe` rows, their number a multiple of the XCD count so that every XCD gets equally many)
+    std::vector<std::vector<uint32_t>> perXcd(kXcds);
+    uint32_t nStripes = (uint32_t)((nBands + stripe * kXcds / 2) / (stripe * kXcds)) * kXcds;
+    if (nStripes < (uint32_t)kXcds) nStripes = kXcds;
+    if (nStripes > nBands) nStripes = std::max<uint32_t>(nBands / kXcds * kXcds, 1);
+    for (size_t i = 0; i < tiles.size(); ++i) perXcd[((uint64_t)bandOf[i] * nStripes / nBands) % kXcds].push_back((uint32_t)i);
+    size_t longest = 0;
+    for (auto& l : perXcd) longest = std::max(longest, l.size());
+    std::vector<uint32_t> order(longest * kXcds, 0xFFFFFFFFu);
+    for (int x = 0; x < kXcds; ++x)
+        for (size_t k = 0; k < perXcd[x].size(); ++k) order[k * kXcds + x] = perXcd[x][k];
+    s.order.allocate(order.size());
+    FA_HIP(hipMemcpyAsync(s.order.get(), order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    s.tiles = std::move(dTiles);
+    s.nt = (uint32_t)sh.nt;
+    s.per = (uint32_t)sh.per;
+    s.kmax = (uint32_t)sh.kmax;
+    s.tileH = tileH;
+    s.tileWMax = sh.tileW;
+    s.nTiles = (uint32_t)tiles.size();
+    s.gridX = (uint32_t)order.size();
+    s.ldsBytes = sh.ldsBytes;
+    s.totalChunks = total;
+    s.stagedCells = total * 4;
+    s.valid = true;
+    return true;
+}
+
+}  // namespace
+
+// Workgroup shape by stencil (tuning: STAGE2_NT / STAGE2_TW / STAGE2_LDS / STAGE2_STRIPE); false: no staged form for this
+// plan (positions without spatial coherence), the caller keeps the gather kernels.
+bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+{
+    if (plan.outX * plan.outY == 0) return false;
+    const bool cubic = plan.kind == PlanKind::Bicubic;
+    // measured on the benchmark plan (profiles/r02_sweep_*.log): 1024 threads on 512 x 8 tiles for the 1 x 1 and 2 x 2 stencils
+    // (one workgroup per CU); the 4 x 4 stencil is arithmetic-bound and prefers 128 x 8 tiles on 512 threads
+    const int nt = tuning("STAGE2_NT", cubic ? 512 : 1024);
+    if (!(nt == 256 || nt == 512 || nt == 1024)) return false;
+    Shape2 sh{};
+    sh.nt = nt;
+    sh.per = cubic ? 2 : 4;
+    // chunks per lane: 1024 threads hold one slot of at most 80 KB
+    sh.kmax = cubic ? (nt == 256 ? 4 : 3) : (nt == 1024 ? 5 : 6);
+    const uint32_t outputs = (uint32_t)(sh.nt * sh.per);
+    sh.tileW = (uint32_t)tuning("STAGE2_TW", cubic ? 64 * (nt / 256) : nt / 2);
+    if (sh.tileW < 32 || sh.tileW % 32 != 0 || outputs % sh.tileW != 0) return false;
+    sh.tileH = outputs / sh.tileW;
+    // LDS of one workgroup: 3 / 2 / 1 workgroups per CU (160 KB)
+    const int ldsDefault = nt == 256 ? 52 : (nt == 512 ? 79 : 159);
+    sh.ldsBytes = (uint32_t)tuning("STAGE2_LDS_KB", ldsDefault) * 1024u;
+    if (sh.ldsBytes > 160u * 1024u - 64u) sh.ldsBytes = 160u * 1024u - 64u;
+    const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", 1));
+    switch (plan.kind) {
+    case PlanKind::Nearest: return build_shape<1>(plan, d_px, d_py, stream, sh, stripe);
+    case PlanKind::Bilinear: return build_shape<2>(plan, d_px, d_py, stream, sh, stripe);
+    case PlanKind::Bicubic: return build_shape<4>(plan, d_px, d_py, stream, sh, stripe);
+    default: return false;
+    }
+}
+
+void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    const Staged2Plan& s = plan.staged2;
+    Staged2Args a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.tiles = s.tiles.get();
+    a.order = s.order.get();
+    a.chunkOff = s.chunkOff.get();
+    a.ldsA = s.ldsA.get();
+    a.ldsB = s.ldsB.get();
+    a.xf = plan.xf.get();
+    a.yf = plan.yf.get();
+    a.xfd = plan.xfd.get();
+    a.yfd = plan.yfd.get();
+    a.outX = (uint32_t)plan.outX;
+    a.outY = (uint32_t)plan.outY;
+    a.tileH = s.tileH;
+    a.inBytes = (uint32_t)(plan.inX * plan.inY * 4);
+    a.nOut = (uint32_t)(plan.outX * plan.outY);
+    a.nz = (uint32_t)nz;
+    // z chunks: workgroups are handed out in order (all tiles of chunk 0, then chunk 1, ...), a CU picks the next one when
+    // it is done; the chunks shrink towards the end of the launch so that the last workgroups are short ones
+    uint32_t zpb = (uint32_t)tuning("STAGE2_ZPB", 50);
+    const uint32_t ztail = (uint32_t)tuning("STAGE2_ZTAIL", 10);  // 0: chunks of one size
+    if (zpb < 1) zpb = 1;
+    if (ceil_div(nz, (size_t)zpb) > (size_t)kMaxZChunks - 6) zpb = (uint32_t)ceil_div(nz, (size_t)kMaxZChunks - 6);
+    uint32_t nChunks = 0;
+    for (uint32_t z = 0; z < nz;) {
+        const uint32_t rem = (uint32_t)nz - z;
+        uint32_t size = zpb;
+        if (ztail > 0 && rem <= 2 * zpb) size = std::max(ztail, (rem + 1) / 2);
+        if (size > rem || rem - size < (ztail + 1) / 2) size = rem;
+        FA_REQUIRE(nChunks < (uint32_t)kMaxZChunks, "too many z chunks for one launch");
+        a.zStart[nChunks++] = z;
+        z += size;
+    }
+    a.zStart[nChunks] = (uint32_t)nz;
+    a.ldsFloats = s.ldsBytes / 4;
+    a.maxDepth = (uint32_t)std::max(2, tuning("STAGE2_DEPTH", 4));
+    a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0);
+    const dim3 grid(s.gridX, nChunks, 1);
+    switch (plan.kind) {
+    case PlanKind::Nearest: launch_shape<1>(s, a, grid, stream); break;
+    case PlanKind::Bilinear: launch_shape<2>(s, a, grid, stream); break;
+    default: launch_shape<4>(s, a, grid, stream); break;
+    }
+    FA_HIP(hipGetLastError());
+}
+
+}  // namespace fimex_amd

@@ -29,7 +29,6 @@
 #include <sstream>
 
 #include "CDMInterpolator.h"
-#include "Projection.h"
 
 using namespace FimexAmd;
 
@@ -94,31 +93,12 @@ public:
     }
 };
 
-// host-only modes (no GPU): the projection code on its own
-//   host_cli --project <src proj4> <dst proj4> <x.f64> <y.f64> <out_dir>     -> out_dir/px.f64, py.f64
-//   host_cli --matrix <in proj4> <out proj4> <outx.f64> <outy.f64> <out_dir>  -> out_dir/matrix.f64 (axes in projection units)
-//   host_cli --method <name>                                                  -> prints the method code
+// host-only mode (no GPU):  host_cli --method <name>  -> prints the method code
 static int hostOnly(int argc, char** argv)
 {
     const std::string mode = argv[1];
     if (mode == "--method" && argc == 3) {
         std::cout << mifi_string_to_interpolation_method(argv[2]) << std::endl;
-        return 0;
-    }
-    if (argc != 7) return 2;
-    const Projection a(argv[2]), b(argv[3]);
-    std::vector<double> x = readAll<double>(argv[4]), y = readAll<double>(argv[5]);
-    const std::string outDir = argv[6];
-    if (mode == "--project") {
-        transform(a, b, x.data(), y.data(), x.size());
-        writeAll(outDir + "/px.f64", x.data(), x.size());
-        writeAll(outDir + "/py.f64", y.data(), y.size());
-        return 0;
-    }
-    if (mode == "--matrix") {
-        std::vector<double> m;
-        vectorReprojectMatrix(a, b, x, y, m);
-        writeAll(outDir + "/matrix.f64", m.data(), m.size());
         return 0;
     }
     return 2;
@@ -233,6 +213,11 @@ int main(int argc, char** argv)
         auto ci = interp.cachedInterpolation();
         std::cout << "inX " << ci->getInX() << " inY " << ci->getInY() << " outX " << ci->getOutX() << " outY " << ci->getOutY();
         if (auto rd = ci->reducedDomain()) std::cout << " reduced xMin " << rd->xMin << " yMin " << rd->yMin;
+        if (ci->amdPlan()) {  // which apply kernel the plan holds: LDS-staged (source cells streamed per slice, widest tile) or gather
+            fimex_amd_plan_info info;
+            if (fimex_amd_regrid_plan_info(ci->amdPlan(), &info) == FIMEX_AMD_OK)
+                std::cout << " stagedCells " << info.stagedCells << " tile " << info.tileW << "x" << info.tileH;
+        }
         std::cout << std::endl;
         for (auto& g : gets) {
             const TypedData out = interp.getTypedDataSlice(g.first, g.second);

@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from fimex_amd import capi as fa
 import cases
+fa.use_tuning_build(True)  # the build that reads the FIMEX_AMD_<NAME> switches
 fa.load(); fa.set_device(0)
 st = torch.cuda.current_stream().cuda_stream
 nx, ny = 3000, 3000

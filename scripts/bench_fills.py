@@ -9,6 +9,7 @@ import torch
 from fimex_amd import capi as fa
 import cases
 nx, ny, nz = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (3000, 3000, 16)
+fa.use_tuning_build(True)  # the build that reads the FIMEX_AMD_<NAME> switches
 fa.load(); fa.set_device(0)
 st = torch.cuda.current_stream().cuda_stream
 h = cases.holes(1, ny, nx, seed=4, frac=0.3)[0]

@@ -86,14 +86,16 @@ __global__ void __launch_bounds__(PRIV ? 256 : NT) tile(Args a)
         }
     }
     const uint32_t rowsPerPass = NT / a.tw;
-    const uint32_t lx = tid % a.tw, ly0 = tid / a.tw;
+    const bool quad = (a.flags & 128) != 0;  // lane owns 4 adjacent cells of one row (PER == 4): one 16-byte store
     uint32_t cellOff[PER], ldsOff[PER];
     float w0[PER], w1[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const uint32_t ly = ly0 + k * rowsPerPass;
+        uint32_t lx = tid % a.tw, ly = tid / a.tw + k * rowsPerPass;
+        if (quad) { lx = 4 * (tid % (a.tw / 4)) + k; ly = tid / (a.tw / 4); }
         const uint32_t x = tx * a.tw + lx, y = ty * a.th + ly;
         cellOff[k] = (x < OX && y < OY) ? (y * OX + x) * 4u : 0xFFFFFFFFu;
+        if (a.flags & 256) cellOff[k] = (tile * NT * PER + ly * a.tw + lx) * 4u;  // tile-contiguous output (upper bound for write locality)
         ldsOff[k] = ((ly * 3 / 2) * cpr * 4 + 2 * lx) * 4u;  // bytes
         w0[k] = 0.25f + 0.001f * (float)lx;
         w1[k] = 0.25f + 0.002f * (float)ly;
@@ -131,21 +133,124 @@ __global__ void __launch_bounds__(PRIV ? 256 : NT) tile(Args a)
             const float* pb = reinterpret_cast<const float*>(cur + ldsOff[k] + cpr * 16);
             s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
         }
+        float rr[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const float top = (1.f - w0[k]) * s00[k] + w0[k] * s01[k];
             const float bot = (1.f - w0[k]) * s10[k] + w0[k] * s11[k];
-            const float r = (1.f - w1[k]) * top + w1[k] * bot;
-            if (a.flags & 8) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+            rr[k] = (1.f - w1[k]) * top + w1[k] * bot;
         }
-        if (NBUF == 1) { /* next iteration's barrier */ }
-        else if (more) wait_vmcnt<(NBUF - 2) * UN + (NBUF - 1) * PER>();
-        else wait_vmcnt<PER>();  // conservative at the tail: everything but this slice's stores
+        if (quad && PER == 4) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 v = {__float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, cellOff[0], 0, 2);
+            if (NBUF == 1) { }
+            else if (more) wait_vmcnt<(NBUF - 2) * UN + (NBUF - 1) * 1>();
+            else wait_vmcnt<1>();
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                if (a.flags & 8) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr[k]), ro, cellOff[k], 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr[k]), ro, cellOff[k], 0, 2);
+            }
+            if (NBUF == 1) { /* next iteration's barrier */ }
+            else if (more) wait_vmcnt<(NBUF - 2) * UN + (NBUF - 1) * PER>();
+            else wait_vmcnt<PER>();  // conservative at the tail: everything but this slice's stores
+        }
         sync();
         slot = (slot + 1 == NBUF) ? 0 : slot + 1;
     }
 }
+
+
+// Results of SB consecutive slices stay in registers and are stored in one burst (SB * PER stores per lane): does the memory
+// system reward longer write bursts per CU?
+template <int NT, int PER, int UN, int NBUF, int SB>
+__global__ void __launch_bounds__(NT) tile_sb(Args a)
+{
+    constexpr uint32_t kSlot = UN * NT * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const uint32_t wave = threadIdx.x / 64;
+    const uint32_t tid = threadIdx.x;
+    uint32_t tile = blockIdx.x;
+    if (tile >= a.nTiles) return;
+    const uint32_t tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const uint32_t nrows = a.th * 3 / 2 + 1, cpr = a.tw / 2 + 1;
+    const uint32_t total = nrows * cpr;
+    const uint32_t r0 = ty * (a.th * 3 / 2), c0 = tx * a.tw * 2;
+    uint32_t gOff[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        const uint32_t c = tid + j * NT;
+        gOff[j] = (c < total) ? ((r0 + c / cpr) * IX + c0 + (c % cpr) * 4u) * 4u : 0xFFFFFFFFu;
+    }
+    const uint32_t rowsPerPass = NT / a.tw;
+    uint32_t cellOff[PER], ldsOff[PER];
+    float w0[PER], w1[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t lx = tid % a.tw, ly = tid / a.tw + k * rowsPerPass;
+        const uint32_t x = tx * a.tw + lx, y = ty * a.th + ly;
+        cellOff[k] = (x < OX && y < OY) ? (y * OX + x) * 4u : 0xFFFFFFFFu;
+        ldsOff[k] = ((ly * 3 / 2) * cpr * 4 + 2 * lx) * 4u;
+        w0[k] = 0.25f + 0.001f * (float)lx;
+        w1[k] = 0.25f + 0.002f * (float)ly;
+    }
+    const uint32_t z0 = blockIdx.y * a.zpb, z1 = min(a.nz, z0 + a.zpb);  // zpb is a multiple of SB
+    const uint32_t inBytes = IX * IY * 4u, outBytes = OX * OY * 4u;
+    const uint32_t waveBase = wave * 64;
+    auto dma = [&](float* dst, uint32_t z) {
+        const rsrc_t rs = make_rsrc(a.in + (size_t)z * IX * IY, inBytes);
+#pragma unroll
+        for (int j = 0; j < UN; ++j) dma16<0>(rs, dst + (waveBase + j * NT) * 4, gOff[j]);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (z0 + i < z1) dma(smem + i * kSlot, z0 + i);
+    wait_vmcnt<(NBUF - 2) * UN>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint32_t slot = 0;
+    for (uint32_t zb = z0; zb < z1; zb += SB) {
+        float rr[SB][PER];
+#pragma unroll
+        for (int sidx = 0; sidx < SB; ++sidx) {
+            const uint32_t z = zb + sidx;
+            const bool more = z + (NBUF - 1) < z1;
+            if (more) dma(smem + ((slot + NBUF - 1) % NBUF) * kSlot, z + (NBUF - 1));
+            const char* cur = reinterpret_cast<const char*>(smem + slot * kSlot);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const float* pa = reinterpret_cast<const float*>(cur + ldsOff[k]);
+                const float* pb = reinterpret_cast<const float*>(cur + ldsOff[k] + cpr * 16);
+                const float top = (1.f - w0[k]) * pa[0] + w0[k] * pa[1];
+                const float bot = (1.f - w0[k]) * pb[0] + w0[k] * pb[1];
+                rr[sidx][k] = (1.f - w1[k]) * top + w1[k] * bot;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (sidx == SB - 1) {  // the burst: SB * PER stores
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const rsrc_t ro = make_rsrc(a.out + (size_t)(zb + q) * OX * OY, outBytes);
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr[q][k]), ro, cellOff[k], 0, 2);
+                }
+            }
+            // slice z + 1 landed: younger are the DMAs of z + 2 .. z + NBUF - 1 and (after a burst) its stores; stores issued
+            // before DMA(z + 1) are older and covered.  Conservative: count only what was certainly issued after DMA(z + 1).
+            if (more) {
+                if (sidx == SB - 1) wait_vmcnt<((NBUF - 2) * UN + SB * PER < 63 ? (NBUF - 2) * UN + SB * PER : 63)>();
+                else wait_vmcnt<(NBUF - 2) * UN>();
+            } else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            slot = (slot + 1 == NBUF) ? 0 : slot + 1;
+        }
+    }
+}
+
+template <int NT, int PER, int UN, int NBUF, int SB>
+static void run_sb(const float* in, float* out, uint32_t nz, uint32_t tw, uint32_t zpb);
 
 // loader / consumer split: waves 0..L-1 only issue DMA (ring of NBUF slots, run ahead), the others only read LDS and store.
 // Hand-off through LDS counters: full[slot] counts loader waves done with a slot generation, free[slot] consumer waves.
@@ -341,6 +446,25 @@ static void run_split(const char* tag, const float* in, float* out, uint32_t nz,
 }
 
 
+
+template <int NT, int PER, int UN, int NBUF, int SB>
+static void run_sb(const float* in, float* out, uint32_t nz, uint32_t tw, uint32_t zpb)
+{
+    Args a{};
+    a.in = in; a.out = out; a.nz = nz; a.zpb = zpb; a.tw = tw; a.th = NT * PER / tw; a.flags = 0;
+    a.tilesX = (OX + tw - 1) / tw;
+    a.nTiles = a.tilesX * ((OY + a.th - 1) / a.th);
+    const uint32_t nrows = a.th * 3 / 2 + 1, cpr = tw / 2 + 1;
+    if (nrows * cpr > (uint32_t)UN * NT) { printf("skip sb: %u chunks > %d\n", nrows * cpr, UN * NT); return; }
+    const size_t lds = (size_t)NBUF * UN * NT * 16;
+    auto kern = tile_sb<NT, PER, UN, NBUF, SB>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid(a.nTiles, (nz + zpb - 1) / zpb);
+    char name[256];
+    snprintf(name, sizeof name, "sb NT%d PER%d UN%d NBUF%d SB%d tw%u th%u zpb%u lds%zu", NT, PER, UN, NBUF, SB, tw, a.th, zpb, lds);
+    run(name, (double)a.nTiles * nrows * cpr * 16.0 * nz, (double)OX * OY * 4.0 * nz, [&] { kern<<<grid, NT, lds>>>(a); });
+}
+
 template <int NT, int PER, int TW>
 struct Shape {
     static constexpr int TH = NT * PER / TW;
@@ -474,6 +598,31 @@ int main(int argc, char** argv)
         run_split<256, 4, 4, 3, 1>("split", in, out, nz, 128, 50, 0);
         run_split<256, 4, 4, 4, 1>("split", in, out, nz, 128, 50, 0);
         run_split<256, 4, 4, 5, 1>("split", in, out, nz, 128, 50, 0);
+    }
+
+    if (want("store")) {
+        for (uint32_t flags : {0u, 128u, 256u, 32u, 32u + 128u, 32u + 256u, 2u}) {
+            run_tile<256, 4, 4, 2, false>("store", in, out, nz, 128, 50, flags);
+            run_tile<256, 4, 4, 3, false>("store", in, out, nz, 128, 50, flags);
+            run_tile<512, 4, 4, 3, false>("store", in, out, nz, 256, 50, flags);
+            run_tile<1024, 4, 4, 2, false>("store", in, out, nz, 512, 50, flags);
+        }
+    }
+
+    if (want("sb")) {
+        run_sb<256, 4, 4, 2, 1>(in, out, nz, 128, 48);
+        run_sb<256, 4, 4, 2, 2>(in, out, nz, 128, 48);
+        run_sb<256, 4, 4, 2, 4>(in, out, nz, 128, 48);
+        run_sb<256, 4, 4, 2, 8>(in, out, nz, 128, 48);
+        run_sb<256, 4, 4, 3, 4>(in, out, nz, 128, 48);
+        run_sb<512, 4, 4, 2, 1>(in, out, nz, 256, 48);
+        run_sb<512, 4, 4, 2, 4>(in, out, nz, 256, 48);
+        run_sb<512, 4, 4, 2, 8>(in, out, nz, 256, 48);
+        run_sb<1024, 4, 4, 2, 1>(in, out, nz, 512, 48);
+        run_sb<1024, 4, 4, 2, 2>(in, out, nz, 512, 48);
+        run_sb<1024, 4, 4, 2, 4>(in, out, nz, 512, 48);
+        run_sb<1024, 4, 4, 2, 8>(in, out, nz, 512, 48);
+        run_sb<1024, 4, 4, 2, 12>(in, out, nz, 512, 48);
     }
     CK(hipFree(in));
     CK(hipFree(out));

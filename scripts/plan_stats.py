@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from fimex_amd import capi as fa
 import workloads
+fa.use_tuning_build(True)  # the build that reads the FIMEX_AMD_<NAME> switches
 fa.load(); fa.set_device(0)
 wl = workloads.BilinearRotatedPole()
 lon, lat = wl.target_lonlat()

@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def tuning_build():
+    """The product library compiles its experiment switches in; tests that force another kernel variant through a
+    FIMEX_AMD_<NAME> switch run on libfimex_amd_tuning.so (same sources, -DFIMEX_AMD_TUNING)."""
+    from fimex_amd import capi
+    was = capi.use_tuning_build(True)
+    yield
+    capi.use_tuning_build(was)

@@ -69,3 +69,16 @@ def test_product_does_not_touch_the_oracle():
                 if re.search(r"\boracle\b|fimex_oracle|orc_", text):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_product_library_has_no_experiment_switches():
+    """The shipped library compiles its measured defaults in: it holds no FIMEX_AMD_<NAME> key to look up in the
+    environment (the ablation switches that skip loads or stores exist in libfimex_amd_tuning.so only), and the tuning build
+    exports the same ABI."""
+    blob = open(capi.LIB_PATH, "rb").read()
+    assert b"FIMEX_AMD_" not in blob
+    tuning = open(capi.TUNING_LIB_PATH, "rb").read()
+    assert b"FIMEX_AMD_" in tuning
+    lib = ctypes.CDLL(capi.TUNING_LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(lib, name), "missing export in the tuning build: " + name

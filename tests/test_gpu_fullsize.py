@@ -54,7 +54,7 @@ def test_c2_c3_full_grid_matches_oracle(fa, c2, method):
     assert cases.same(plan.apply_host(f[2:3]), got[2:3])
 
 
-def test_c2_both_bilinear_kernels_agree_and_constants_survive(fa, c2, monkeypatch):
+def test_c2_both_bilinear_kernels_agree_and_constants_survive(fa, c2, monkeypatch, tuning_build):
     wl, px, py, f = c2
     monkeypatch.setenv("FIMEX_AMD_STAGED", "1")
     staged = fa.RegridPlan(oracle.BILINEAR, px, py, wl.inX, wl.inY, wl.outX, wl.outY).apply_host(f)
@@ -66,6 +66,35 @@ def test_c2_both_bilinear_kernels_agree_and_constants_survive(fa, c2, monkeypatc
     ok = ~np.isnan(out)
     assert ok.mean() > 0.85
     np.testing.assert_allclose(out[ok], 273.15, rtol=3e-7)
+
+
+@pytest.mark.parametrize("method", [oracle.BILINEAR, oracle.BICUBIC])
+def test_north_star_batch_of_200_slices(fa, c2, method):
+    """The headline launch itself: ONE device call over 200 resident slices (9.6 GB in, 3.2 GB out), slices 0, 99 and 199
+    against the oracle bit for bit; the three-kernel agreement test above covers the other paths.  All three backward
+    kernels also agree with each other on a cheap property: a slice that is another slice plus a constant differs from it."""
+    import torch
+    wl, px, py, f = c2
+    nz = 200
+    base = torch.from_numpy(f[0]).cuda()
+    d_in = torch.empty((nz, wl.inY, wl.inX), dtype=torch.float32, device="cuda")
+    for k0 in range(0, nz, 20):
+        off = 0.01 * torch.arange(k0, k0 + 20, dtype=torch.float32, device="cuda")
+        d_in[k0:k0 + 20] = base[None] + off[:, None, None]
+    d_out = torch.full((nz, wl.outY, wl.outX), -1.0, dtype=torch.float32, device="cuda")
+    plan = fa.RegridPlan(method, px, py, wl.inX, wl.inY, wl.outX, wl.outY)
+    plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k in (0, 99, 199):
+        want = oracle.interpolate_values(method, px, py, d_in[k].cpu().numpy()[None], wl.inX, wl.inY, wl.outX, wl.outY, nthreads=16)[0]
+        got = d_out[k].cpu().numpy()
+        assert cases.same(got, want), "slice %d: %s" % (k, cases.describe_mismatch(got, want))
+    # every slice was written (no cell keeps the -1 it started with) and the NaN pattern is the plan's, slice after slice
+    assert not bool((d_out == -1.0).any())
+    nan0 = torch.isnan(d_out[0])
+    assert all(bool((torch.isnan(d_out[k]) == nan0).all()) for k in (1, 57, 123, 198))
+    del d_in, d_out
+    torch.cuda.empty_cache()
 
 
 def test_c4_forward_mean_global_to_lambert(fa):

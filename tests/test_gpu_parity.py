@@ -69,7 +69,7 @@ def test_backward_ragged_z_counts(fa, method, nz):
                                    {"STAGED": "1", "STAGE_TW": "32", "STAGE_ZPB": "3"},
                                    {"STAGED": "1", "STAGE_TW": "256", "STAGE_ZPB": "1", "XCD": "1"},
                                    {"STAGED": "1", "XCD": "3", "STAGED_MIN_NZ": "1"}])
-def test_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, method, shape, knobs):
+def test_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, method, shape, knobs, tuning_build):
     """Both kernels of nearest, bilinear and bicubic (per-lane gather, LDS-staged tiles) on source widths that allow staging
     (inX % 4 == 0): shrinking (several source cells per target cell), magnifying, and strongly anisotropic geometries,
     different tile shapes, z chunkings and tile orders."""
@@ -205,7 +205,7 @@ def test_vector_rotation_90_degrees(fa):
                                    (64, 66, 1), (33, 1200, 1), (1000, 131, 1), (5000, 1100, 1)])
 @pytest.mark.parametrize("params", [(4.0, 1.6, 100), (0.5, 1.0, 23), (4.0, 1.9, 3), (1e-9, 1.6, 41)])
 @pytest.mark.parametrize("geometry", ["1", "2"], ids=["16waves_x_16columns", "8waves_x_32columns"])
-def test_fill2d_matches_oracle(fa, monkeypatch, shape, params, geometry):
+def test_fill2d_matches_oracle(fa, monkeypatch, shape, params, geometry, tuning_build):
     """Both band geometries of the systolic kernel (the launcher picks by batch size) against the CPU restatement."""
     nx, ny, nz = shape
     relaxCrit, corrEff, maxLoop = params
@@ -224,7 +224,7 @@ def _oracle_fill2d(nx, ny, nz, z, relaxCrit, corrEff, maxLoop):
     return oracle.fill2d(cases.holes(nz, ny, nx, seed=nx * 31 + ny)[z], relaxCrit, corrEff, maxLoop)
 
 
-def test_fill2d_geometry_follows_the_batch_size(fa, monkeypatch):
+def test_fill2d_geometry_follows_the_batch_size(fa, monkeypatch, tuning_build):
     """Eight slices and more run the 8-wave, 32-column geometry by default; the result does not depend on it."""
     f = np.stack([cases.holes(1, 90, 140, seed=5)[0]] * 50)
     want, wn, rc = oracle.fill2d(f[0], 4.0, 1.6, 40)
@@ -254,7 +254,7 @@ def test_creepfill_matches_oracle(fa, shape, params):
 
 
 @pytest.mark.parametrize("algo", ["0", "1", "2"], ids=["add_chain", "one_workgroup", "whole_chip"])
-def test_fills_with_each_evaluation_of_the_sums(fa, monkeypatch, algo):
+def test_fills_with_each_evaluation_of_the_sums(fa, monkeypatch, algo, tuning_build):
     """The first-guess sums (mean, mean absolute deviation) as an add chain, binade-parallel in one workgroup per slice
     (batches of 100 slices and more) and binade-parallel over the whole chip (smaller batches): the same bits."""
     monkeypatch.setenv("FIMEX_AMD_SUM_ALGO", algo)
@@ -319,7 +319,7 @@ def test_sor_error_is_the_reference_expression(fa):
             assert rc == oracle.OK and nch[0] == wn and cases.same(got[0], want), (case, corr, cases.describe_mismatch(got[0], want))
 
 
-def test_fills_on_random_shapes(fa, monkeypatch):
+def test_fills_on_random_shapes(fa, monkeypatch, tuning_build):
     """Forty slices of random size, hole pattern and parameters through both band geometries and all three fills:
     every width class of the systolic kernels (narrower than a chunk, one band, ragged last band, several hand-off
     windows) meets the CPU restatement."""
@@ -346,7 +346,7 @@ def test_fills_on_random_shapes(fa, monkeypatch):
         assert rc == oracle.OK and nchc[0] == wnc and cases.same(gotc[0], wantc), (case, nx, ny, repeat, weight, cases.describe_mismatch(gotc[0], wantc))
 
 
-def test_fill2d_both_kernels_agree(fa, monkeypatch):
+def test_fill2d_both_kernels_agree(fa, monkeypatch, tuning_build):
     """The systolic row-band kernel and the anti-diagonal wavefront kernel are two implementations of the same order."""
     f = cases.holes(2, 150, 210, seed=77)
     monkeypatch.setenv("FIMEX_AMD_FILL_V2", "1")
@@ -356,7 +356,7 @@ def test_fill2d_both_kernels_agree(fa, monkeypatch):
     assert na == nb and cases.same(a, b)
 
 
-def test_creepfill_both_kernels_agree(fa, monkeypatch):
+def test_creepfill_both_kernels_agree(fa, monkeypatch, tuning_build):
     """Row-band kernel with mask generations against the wavefront kernel with per-cell counters; a hole that reaches the
     lower right corner creeps one cell per sweep, so the sweep count goes well beyond repeat."""
     f = cases.holes(2, 170, 230, seed=78)
@@ -758,7 +758,7 @@ def test_coord_search_rejects_bad_arguments(fa):
 @pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
 @pytest.mark.parametrize("dt,bad", [(np.int16, -32767.0), (np.uint16, 65535.0), (np.int8, -127.0), (np.uint8, 255.0), (np.int32, -2147483647.0),
                                     (np.float32, 9.96921e36), (np.float64, -1e30), (np.int64, -9.0e18)])
-def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, bad):
+def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, bad, tuning_build):
     """fimex_amd_regrid_apply_typed_device: one kernel on the stored type for the small integer types, three passes for the
     others, both against the oracle's three steps; the fused and the unfused GPU paths agree as well."""
     import torch

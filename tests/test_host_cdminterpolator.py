@@ -17,7 +17,7 @@ from oracle import proj_oracle as po
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "fimex_amd", "host_cli.so")
+CLI = os.path.join(ROOT, "fimex_amd", "host_cli")
 GEO = "+proj=latlong +R=6371000"
 FILL_FLOAT = 9.9692099683868690e+36  # MIFI_FILL_FLOAT: CDM::getFillValue of a float variable without _FillValue (src/CDM.cc:490-518)
 
@@ -498,3 +498,58 @@ def test_two_coordinate_systems_fixture(tmp_path, golden_dir):
         assert np.array_equal(got, want.ravel())
     inside = (results["coord_kdtree"] != -32767) & (results["nearestneighbor"] != -32767)
     assert inside.sum() > 100 and np.array_equal(results["coord_kdtree"][inside], results["nearestneighbor"][inside])
+
+
+@pytest.mark.parametrize("method,code", [("bilinear", oracle.BILINEAR), ("nearestneighbor", oracle.NEAREST), ("bicubic", oracle.BICUBIC)])
+def test_reduced_domain_crop_through_the_staged_kernels(tmp_path, method, code):
+    """SURVEY 8 row a5: CachedInterpolation::createReducedDomain + the cropped read of getInputDataSlice
+    (src/CachedInterpolation.cc:44-90,159-200) with a target strictly inside a 1201 x 1003 source.  The crop starts at
+    xMin, yMin > 0 and has an odd width, and the LDS-staged kernels run on it (row segments aligned per row); the result
+    equals the oracle on the UNCROPPED source, the crop equals orc_create_reduced_domain."""
+    import re
+    NX, NY, OX, OY, NL = 1201, 1003, 300, 200, 5
+    slon, slat = -30.0 + 0.05 * np.arange(NX), 40.0 + 0.03 * np.arange(NY)
+    slon.tofile(tmp_path / "x.f64")
+    slat.tofile(tmp_path / "y.f64")
+    tlon = np.linspace(-30.0 + 0.05 * 400.3, -30.0 + 0.05 * 700.9, OX)
+    tlat = np.linspace(40.0 + 0.03 * 250.7, 40.0 + 0.03 * 600.2, OY)
+    tlon.tofile(tmp_path / "ox.f64")
+    tlat.tofile(tmp_path / "oy.f64")
+    f = cases.field(NL, NY, NX, seed=11)
+    f.tofile(tmp_path / "t.f32")
+    packed = np.random.default_rng(12).integers(-3000, 3000, (NL, NY, NX)).astype(np.int16)
+    packed[:, ::37, ::41] = -32767
+    packed.tofile(tmp_path / "p.i16")
+    lines = ["proj " + GEO, "xaxis %s" % (tmp_path / "x.f64"), "yaxis %s" % (tmp_path / "y.f64"), "method " + method, "outproj " + GEO,
+             "outx %s degrees_east" % (tmp_path / "ox.f64"), "outy %s degrees_north" % (tmp_path / "oy.f64"),
+             "var t %d %s nan" % (NL, tmp_path / "t.f32"), "var p %d %s -32767 type short" % (NL, tmp_path / "p.i16"), "get t 0", "get p 0"]
+    out, stdout = _run(tmp_path, lines)
+    m = re.search(r"inX (\d+) inY (\d+) outX (\d+) outY (\d+) reduced xMin (\d+) yMin (\d+) stagedCells (\d+) tile (\d+)x(\d+)", stdout)
+    assert m, stdout
+    inX, inY, outX, outY, xMin, yMin, staged, tw, th = map(int, m.groups())
+    # the positions on the full grid, then the reference's crop of them
+    fx = oracle.points2position(np.radians(np.tile(tlon, OY)), np.radians(slon), oracle.LONGITUDE)
+    fy = oracle.points2position(np.radians(np.repeat(tlat, OX)), np.radians(slat), oracle.LATITUDE)
+    rd = oracle.create_reduced_domain(fx, fy, NX, NY)
+    assert rd is not None
+    assert (xMin, yMin, inX, inY) == (rd["xMin"], rd["yMin"], rd["inX"], rd["inY"])
+    assert xMin > 300 and yMin > 200 and inX < 400 and inY < 400 and inX % 4 != 0, (xMin, yMin, inX, inY)
+    assert (outX, outY) == (OX, OY)
+    assert staged > 0 and tw > 0, "the cropped grid did not get an LDS-staged plan: " + stdout
+    px, py = np.fromfile(out / "points_x.f64"), np.fromfile(out / "points_y.f64")
+    # CDMInterpolator keeps the positions on the full grid; the plan holds them minus the crop's origin
+    np.testing.assert_allclose(px, fx, atol=1e-7)
+    np.testing.assert_allclose(py, fy, atol=1e-7)
+    np.testing.assert_allclose(px - xMin, rd["px"], atol=1e-7)
+    # subtracting the integer offset is exact in double, so floor and fraction of every position survive the crop:
+    # the oracle on the uncropped source with the uncropped positions must give the same bits
+    want = oracle.interpolate_values(code, px, py, f, NX, NY, OX, OY)
+    got = np.fromfile(out / "t_0.f32", dtype=np.float32).reshape(NL, OY, OX)
+    want = oracle.interpolation_array2data(want, oracle.CDM_FLOAT, FILL_FLOAT)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.isfinite(got).mean() > 0.9
+    # the same through the stored type (packed shorts with a fill value; odd crop width: the gather form on the stored type)
+    wf = oracle.interpolate_values(code, px, py, oracle.data2interpolation_array(packed, -32767.0), NX, NY, OX, OY)
+    wantp = oracle.interpolation_array2data(wf, oracle.CDM_SHORT, -32767.0)
+    gotp = np.fromfile(out / "p_0.raw", dtype=np.int16).reshape(NL, OY, OX)
+    np.testing.assert_array_equal(gotp, wantp)

@@ -10,7 +10,8 @@ import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run(cmd, **kw):
-    r = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    print("run:", " ".join(cmd[:7]), "...", flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, **kw)
     if r.returncode != 0:
         print(r.stdout[-3000:], r.stderr[-3000:]); sys.exit(1)
     return r

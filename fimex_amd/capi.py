@@ -21,6 +21,7 @@ NEAREST_NEIGHBOR, BILINEAR, BICUBIC, COORD_NN, COORD_NN_KD = 0, 1, 2, 3, 4
 FORWARD_SUM, FORWARD_MEAN, FORWARD_MEDIAN, FORWARD_MAX, FORWARD_MIN = 5, 6, 7, 8, 9
 FORWARD_UNDEF_SUM, FORWARD_UNDEF_MEAN, FORWARD_UNDEF_MEDIAN, FORWARD_UNDEF_MAX, FORWARD_UNDEF_MIN = 10, 11, 12, 13, 14
 PROJ_AXIS, LONGITUDE, LATITUDE = 0, 1, 2
+BICUBIC_REFERENCE, BICUBIC_FAST = 0, 1
 
 
 class FimexAmdError(RuntimeError):
@@ -57,6 +58,8 @@ SYMBOLS = {
     "fimex_amd_set_device": (ctypes.c_int, [ctypes.c_int]),
     "fimex_amd_regrid_plan_create": (ctypes.c_int, [ctypes.c_int, _D, _D, _Z, _Z, _Z, _Z, _Z, ctypes.POINTER(_V)]),
     "fimex_amd_regrid_plan_create_device": (ctypes.c_int, [ctypes.c_int, _V, _V, _Z, _Z, _Z, _Z, _Z, _V, ctypes.POINTER(_V)]),
+    "fimex_amd_regrid_plan_create_opt": (ctypes.c_int, [ctypes.c_int, _D, _D, _Z, _Z, _Z, _Z, _Z, ctypes.c_int, ctypes.POINTER(_V)]),
+    "fimex_amd_regrid_plan_create_device_opt": (ctypes.c_int, [ctypes.c_int, _V, _V, _Z, _Z, _Z, _Z, _Z, ctypes.c_int, _V, ctypes.POINTER(_V)]),
     "fimex_amd_regrid_plan_destroy": (ctypes.c_int, [_V]),
     "fimex_amd_regrid_plan_info": (ctypes.c_int, [_V, ctypes.POINTER(PlanInfo)]),
     "fimex_amd_regrid_apply_host": (ctypes.c_int, [_V, _F, _Z, _F, _Z, _ZP]),
@@ -185,22 +188,30 @@ def _dp(a):
 class RegridPlan:
     """fimex_amd_regrid_plan: backward (per output cell) or forward (per input cell) positions."""
 
-    def __init__(self, funcType, pointsOnXAxis, pointsOnYAxis, inX, inY, outX, outY):
+    def __init__(self, funcType, pointsOnXAxis, pointsOnYAxis, inX, inY, outX, outY, bicubic=None):
         px, py = _f64(pointsOnXAxis).ravel(), _f64(pointsOnYAxis).ravel()
         if px.size != py.size:
             raise ValueError("position arrays differ in size")
         self._h = _V()
         self.inX, self.inY, self.outX, self.outY = inX, inY, outX, outY
-        _check(load().fimex_amd_regrid_plan_create(funcType, _dp(px), _dp(py), px.size, inX, inY, outX, outY,
-                                                   ctypes.byref(self._h)))
+        if bicubic is None:
+            _check(load().fimex_amd_regrid_plan_create(funcType, _dp(px), _dp(py), px.size, inX, inY, outX, outY,
+                                                       ctypes.byref(self._h)))
+        else:  # BICUBIC_REFERENCE / BICUBIC_FAST
+            _check(load().fimex_amd_regrid_plan_create_opt(funcType, _dp(px), _dp(py), px.size, inX, inY, outX, outY, bicubic,
+                                                           ctypes.byref(self._h)))
 
     @classmethod
-    def from_device(cls, funcType, d_px, d_py, nPoints, inX, inY, outX, outY, stream=0):
+    def from_device(cls, funcType, d_px, d_py, nPoints, inX, inY, outX, outY, stream=0, bicubic=None):
         self = cls.__new__(cls)
         self._h = _V()
         self.inX, self.inY, self.outX, self.outY = inX, inY, outX, outY
-        _check(load().fimex_amd_regrid_plan_create_device(funcType, d_px, d_py, nPoints, inX, inY, outX, outY,
-                                                          stream, ctypes.byref(self._h)))
+        if bicubic is None:
+            _check(load().fimex_amd_regrid_plan_create_device(funcType, d_px, d_py, nPoints, inX, inY, outX, outY,
+                                                              stream, ctypes.byref(self._h)))
+        else:
+            _check(load().fimex_amd_regrid_plan_create_device_opt(funcType, d_px, d_py, nPoints, inX, inY, outX, outY, bicubic,
+                                                                  stream, ctypes.byref(self._h)))
         return self
 
     def close(self):

@@ -149,7 +149,7 @@ extern "C" {
 
 const char* fimex_amd_last_error(void) { return g_lastError.c_str(); }
 
-int fimex_amd_abi_version(void) { return 110; }  // 1.10: typed slices, projections, coordinate search, 1-D blends added to 1.00
+int fimex_amd_abi_version(void) { return 120; }  // 1.20: plan constructors with the bicubic arithmetic, release of cached buffers
 
 int fimex_amd_device_count(void) { return usable_device_count(); }
 
@@ -164,11 +164,31 @@ int fimex_amd_set_device(int ordinal)
 int fimex_amd_regrid_plan_create(int funcType, const double* px, const double* py, size_t nPoints, size_t inX, size_t inY,
                                  size_t outX, size_t outY, fimex_amd_regrid_plan** out)
 {
+    return fimex_amd_regrid_plan_create_opt(funcType, px, py, nPoints, inX, inY, outX, outY, FIMEX_AMD_BICUBIC_REFERENCE, out);
+}
+
+int fimex_amd_regrid_plan_create_device(int funcType, const double* d_px, const double* d_py, size_t nPoints, size_t inX,
+                                        size_t inY, size_t outX, size_t outY, void* stream, fimex_amd_regrid_plan** out)
+{
+    return fimex_amd_regrid_plan_create_device_opt(funcType, d_px, d_py, nPoints, inX, inY, outX, outY, FIMEX_AMD_BICUBIC_REFERENCE, stream, out);
+}
+
+static void set_arithmetic(fimex_amd_regrid_plan& plan, int bicubicArithmetic)
+{
+    FA_REQUIRE(bicubicArithmetic == FIMEX_AMD_BICUBIC_REFERENCE || bicubicArithmetic == FIMEX_AMD_BICUBIC_FAST,
+               "unknown bicubic arithmetic: " + std::to_string(bicubicArithmetic));
+    plan.bicubicFast = plan.kind == PlanKind::Bicubic && bicubicArithmetic == FIMEX_AMD_BICUBIC_FAST;
+}
+
+int fimex_amd_regrid_plan_create_opt(int funcType, const double* px, const double* py, size_t nPoints, size_t inX, size_t inY,
+                                     size_t outX, size_t outY, int bicubicArithmetic, fimex_amd_regrid_plan** out)
+{
     return c_guard([&] {
         FA_REQUIRE(out != nullptr, "plan output pointer is NULL");
         *out = nullptr;
         FA_REQUIRE(px != nullptr && py != nullptr, "position arrays are NULL");
         auto plan = new_plan(funcType, nPoints, inX, inY, outX, outY);
+        set_arithmetic(*plan, bicubicArithmetic);
         ScopedStream stream;
         DeviceArray<double> d_px(nPoints), d_py(nPoints);
         host_to_device(d_px.get(), px, nPoints * sizeof(double), stream.get());
@@ -179,14 +199,16 @@ int fimex_amd_regrid_plan_create(int funcType, const double* px, const double* p
     });
 }
 
-int fimex_amd_regrid_plan_create_device(int funcType, const double* d_px, const double* d_py, size_t nPoints, size_t inX,
-                                        size_t inY, size_t outX, size_t outY, void* stream, fimex_amd_regrid_plan** out)
+int fimex_amd_regrid_plan_create_device_opt(int funcType, const double* d_px, const double* d_py, size_t nPoints, size_t inX,
+                                            size_t inY, size_t outX, size_t outY, int bicubicArithmetic, void* stream,
+                                            fimex_amd_regrid_plan** out)
 {
     return c_guard([&] {
         FA_REQUIRE(out != nullptr, "plan output pointer is NULL");
         *out = nullptr;
         FA_REQUIRE(d_px != nullptr && d_py != nullptr, "position arrays are NULL");
         auto plan = new_plan(funcType, nPoints, inX, inY, outX, outY);
+        set_arithmetic(*plan, bicubicArithmetic);
         build_plan(*plan, d_px, d_py, as_stream(stream));
         *out = plan.release();
     });

@@ -70,6 +70,7 @@ struct fimex_amd_regrid_plan {
     int funcType = 0;
     int device = 0;
     fimex_amd::PlanKind kind = fimex_amd::PlanKind::Nearest;
+    bool bicubicFast = false;  // FIMEX_AMD_BICUBIC_FAST: float fused multiply-adds in the LDS-staged bicubic kernel
     size_t inX = 0, inY = 0, outX = 0, outY = 0;
 
     // backward plans

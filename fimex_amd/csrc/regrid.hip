@@ -588,7 +588,7 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
     // (bicubic keeps the first form where it exists -- 32 x 16 tiles at four workgroups per CU suit its arithmetic -- and takes
     // the second one for the source widths the first cannot stage, inX % 4 != 0)
     const int second = tuning("STAGED2", 1);
-    const bool wantSecond = second >= 2 || (second == 1 && (plan.kind != PlanKind::Bicubic || !plan.staged.valid));
+    const bool wantSecond = second >= 2 || (second == 1 && (plan.kind != PlanKind::Bicubic || !plan.staged.valid || plan.bicubicFast));
     if (tuning("STAGED", 1) != 0 && wantSecond && build_staged2_plan(plan, d_px, d_py, stream)) {
         const auto& s = plan.staged2;
         const size_t perCell = plan.kind == PlanKind::Nearest ? 0 : (plan.kind == PlanKind::Bilinear ? plan.xf.bytes() + plan.yf.bytes()
@@ -605,7 +605,9 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
     if (nz == 0) return;
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
     // the staged kernel pays a per-tile set-up (row table, chunk list) that only amortises over a few slices
-    if (plan.staged2.valid && tuning("STAGED", 1) != 0 && tuning("STAGED2", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
+    // (a bicubic plan in the reference's arithmetic that holds both forms runs the first one)
+    const bool second = plan.staged2.valid && (plan.kind != PlanKind::Bicubic || plan.bicubicFast || !plan.staged.valid || tuning("STAGED2", 1) >= 2);
+    if (second && tuning("STAGED", 1) != 0 && tuning("STAGED2", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
         launch_staged2_apply(plan, d_in, nz, d_out, stream);
         return;
     }

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ p
     __shared__ uint32_t rowChunk[kMaxRows + 1];
     const uint32_t t = blockIdx.x;
     const StagedTile T = tiles[t];
+    if (T.rsv[0] != 0) return;  // not staged (see build_shape)
     const uint32_t nCells = T.w * tileH;
     if (threadIdx.x == 0) { shRmin = 0x7FFFFFFF; shRmax = -1; shFail = 0; }
     __syncthreads();
@@ -136,11 +137,13 @@ struct Staged2Args {
     const uint32_t* chunkOff;
     const uint32_t* ldsA;
     const uint32_t* ldsB;
+    const uint32_t* pos;  // gather plan (regrid.hip): source cell of the stencil's corner, for the tiles that are not staged
     const float* xf;
     const float* yf;
     const double* xfd;
     const double* yfd;
     uint32_t outX, outY, tileH;
+    uint32_t inX;
     uint32_t inBytes;    // one source slice
     uint32_t nOut;
     uint32_t nz;
@@ -167,7 +170,10 @@ __device__ __forceinline__ void wait_vmcnt_dyn(uint32_t n)
 
 // STENCIL: 1 nearest, 2 bilinear, 4 bicubic; NT: threads of the workgroup; PER: outputs per lane (tile = NT * PER outputs);
 // KMAX: most 16-byte chunks a lane stages per slice.
-template <int STENCIL, int NT, int PER, int KMAX>
+// FAST (bicubic only): the weights rounded to float and float fused multiply-adds instead of the reference's double products
+// accumulated into a float (interpolation.c:1005-1019) -- not bit-identical, within 1e-5 of the stencil's magnitude (the
+// tolerance BASELINE.json states), chosen per plan (FIMEX_AMD_BICUBIC_FAST).
+template <int STENCIL, int NT, int PER, int KMAX, bool FAST = false>
 __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -219,6 +225,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
     uint32_t row[PER][STENCIL];
     float xf[PER], yf[PER];
     double XM[PER][4], MY[PER][4];
+    float XMf[PER][4], MYf[PER][4];
     bool undef[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -244,7 +251,70 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
             row[k][3] = undef[k] ? 0u : (pb >> 16) * 4u;
             cubic_weights(fx, XM[k]);
             cubic_weights(fy, MY[k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { XMf[k][j] = (float)XM[k][j]; MYf[k][j] = (float)MY[k][j]; }
         }
+    }
+    if (T.rsv[0] != 0) {
+        // A tile whose footprint does not fit a slot even at the smallest width (an outlier among its positions: a grid
+        // that wraps around the date line, isolated special points) reads its stencils straight from memory, like the
+        // gather kernels of regrid.hip; every other tile of the plan stays staged.
+        uint32_t p[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            p[k] = (cellOff[k] != 0xFFFFFFFFu) ? a.pos[cellOff[k] / 4u] : kInvalidPos;
+            undef[k] = p[k] == kInvalidPos;
+            if (undef[k]) p[k] = 0;
+        }
+        const uint32_t inRec = (kTuningBuild && (a.flags & 1)) ? 0u : a.inBytes;
+        for (uint32_t z = z0; z < z1; ++z) {
+            const rsrc_t rs = make_rsrc(inBase + (size_t)z * a.inBytes, inRec);
+            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+            auto ld = [&](uint32_t cell) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cell * 4u, 0, 0)); };
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                float r;
+                if constexpr (STENCIL == 1) {
+                    r = ld(p[k]);
+                } else if constexpr (STENCIL == 2) {
+                    const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
+                    const uint32_t dx = nnx ? 0u : 1u, dy = nny ? 0u : a.inX;  // a missing neighbour repeats the cell itself
+                    const float s00 = ld(p[k]), s01 = ld(p[k] + dx), s10 = ld(p[k] + dy), s11 = ld(p[k] + dx + dy);
+                    const float top = (1.f - xf[k]) * s00 + xf[k] * s01;
+                    const float bot = (1.f - xf[k]) * s10 + xf[k] * s11;
+                    const float inter = (1.f - yf[k]) * top + yf[k] * bot;
+                    const float liny = (1 - yf[k]) * s00 + (yf[k] * s10);
+                    r = nnx ? (nny ? s00 : liny) : (nny ? top : inter);
+                } else {
+                    float f[4][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[q][j] = ld(p[k] + q * a.inX + j);
+                    float acc = 0;
+                    if constexpr (FAST) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float xmf = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) xmf = __builtin_fmaf(XMf[k][j], f[q][j], xmf);
+                            acc = __builtin_fmaf(xmf, MYf[k][q], acc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            double xmf = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[q][j];
+                            acc = (float)((double)acc + xmf * MY[k][q]);
+                        }
+                    }
+                    r = acc;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(undef[k] ? undefined_f() : r), ro, cellOff[k], 0, 2);
+            }
+        }
+        return;
     }
     if (T.nChunks == 0) {  // nothing of the source is needed: every output of the tile is undefined
         for (uint32_t z = z0; z < z1; ++z) {
@@ -305,12 +375,22 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                     for (int j = 0; j < 4; ++j) f[r][j] = *reinterpret_cast<const float*>(curb + row[k][r] + 4 * j);
                 }
                 float acc = 0;  // interpolation.c:1005: accumulates into the float output
+                if constexpr (FAST) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double xmf = 0;
+                    for (int r = 0; r < 4; ++r) {
+                        float xmf = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[r][j];  // :1015
-                    acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
+                        for (int j = 0; j < 4; ++j) xmf = __builtin_fmaf(XMf[k][j], f[r][j], xmf);
+                        acc = __builtin_fmaf(xmf, MYf[k][r], acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double xmf = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[r][j];  // :1015
+                        acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(undef[k] ? undefined_f() : acc), ro, cellOff[k], 0, 2);
             }
@@ -335,24 +415,24 @@ struct Shape2 {
     uint32_t ldsBytes;
 };
 
-template <int STENCIL, int NT, int PER, int KMAX>
+template <int STENCIL, int NT, int PER, int KMAX, bool FAST = false>
 void launch_one(const Staged2Args& a, dim3 grid, size_t ldsBytes, hipStream_t stream)
 {
-    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply2<STENCIL, NT, PER, KMAX>), ldsBytes);
-    staged_apply2<STENCIL, NT, PER, KMAX><<<grid, NT, ldsBytes, stream>>>(a);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply2<STENCIL, NT, PER, KMAX, FAST>), ldsBytes);
+    staged_apply2<STENCIL, NT, PER, KMAX, FAST><<<grid, NT, ldsBytes, stream>>>(a);
 }
 
-template <int STENCIL>
+template <int STENCIL, bool FAST = false>
 void launch_shape(const Staged2Plan& s, const Staged2Args& a, dim3 grid, hipStream_t stream)
 {
     const uint32_t key = s.nt * 10000 + s.per * 100 + s.kmax;
     switch (key) {
-    case 2560406: launch_one<STENCIL, 256, 4, 6>(a, grid, s.ldsBytes, stream); break;
-    case 5120406: launch_one<STENCIL, 512, 4, 6>(a, grid, s.ldsBytes, stream); break;
-    case 10240405: launch_one<STENCIL, 1024, 4, 5>(a, grid, s.ldsBytes, stream); break;
-    case 5120203: launch_one<STENCIL, 512, 2, 3>(a, grid, s.ldsBytes, stream); break;
-    case 10240203: launch_one<STENCIL, 1024, 2, 3>(a, grid, s.ldsBytes, stream); break;
-    case 2560204: launch_one<STENCIL, 256, 2, 4>(a, grid, s.ldsBytes, stream); break;
+    case 2560406: launch_one<STENCIL, 256, 4, 6, FAST>(a, grid, s.ldsBytes, stream); break;
+    case 5120406: launch_one<STENCIL, 512, 4, 6, FAST>(a, grid, s.ldsBytes, stream); break;
+    case 10240405: launch_one<STENCIL, 1024, 4, 5, FAST>(a, grid, s.ldsBytes, stream); break;
+    case 5120203: launch_one<STENCIL, 512, 2, 3, FAST>(a, grid, s.ldsBytes, stream); break;
+    case 10240203: launch_one<STENCIL, 1024, 2, 3, FAST>(a, grid, s.ldsBytes, stream); break;
+    case 2560204: launch_one<STENCIL, 256, 2, 4, FAST>(a, grid, s.ldsBytes, stream); break;
     default: throw Error("staged2: unexpected workgroup shape");
     }
 }
@@ -368,22 +448,31 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
     cap = std::min<uint32_t>(cap & ~63u, (uint32_t)sh.kmax * sh.nt);
     cap = std::min<uint32_t>(cap, 16383u);  // 16-bit LDS offsets in floats
     const uint32_t step = sh.tileW >= 128 ? 64u : 32u;  // tile widths are multiples of this (a wave stores 64 consecutive cells)
-    std::vector<uint32_t> bandW(nBands, std::min(sh.tileW, (outX + step - 1) / step * step));
+    // Tiles: every tile row starts as tiles of the widest shape.  A tile that does not fit (too many chunks for a slot, too
+    // many source rows) makes its row narrower when most tiles of the row fail (the row's cells cover more source: rows near
+    // the pole of the benchmark plan), otherwise it is split in two; at the narrowest width it becomes a gather tile
+    // (rsv[0] = 1: the kernel reads its stencils from memory).  More than 1/8 of the cells that way: no staged plan.
+    const uint32_t widest = std::min(sh.tileW, (outX + step - 1) / step * step);
     std::vector<StagedTile> tiles;
     std::vector<uint32_t> bandOf;
+    auto uniform_row = [&](uint32_t b, uint32_t w, std::vector<StagedTile>& out) {
+        for (uint32_t x0 = 0; x0 < outX; x0 += w) {
+            StagedTile t{};
+            t.x0 = x0;
+            t.y0 = b * tileH;
+            t.w = std::min(w, outX - x0);
+            out.push_back(t);
+        }
+    };
+    std::vector<std::vector<StagedTile>> rows(nBands);
+    std::vector<uint32_t> rowW(nBands, widest);
+    for (uint32_t b = 0; b < nBands; ++b) uniform_row(b, widest, rows[b]);
     DeviceArray<StagedTile> dTiles;
     for (int pass = 0;; ++pass) {
         tiles.clear();
         bandOf.clear();
         for (uint32_t b = 0; b < nBands; ++b)
-            for (uint32_t x0 = 0; x0 < outX; x0 += bandW[b]) {
-                StagedTile t{};
-                t.x0 = x0;
-                t.y0 = b * tileH;
-                t.w = std::min(bandW[b], outX - x0);
-                tiles.push_back(t);
-                bandOf.push_back(b);
-            }
+            for (const StagedTile& t : rows[b]) { tiles.push_back(t); bandOf.push_back(b); }
         if (tiles.size() > 0x7FFFFFFFu / 8) return false;
         dTiles.allocate(tiles.size());
         FA_HIP(hipMemcpyAsync(dTiles.get(), tiles.data(), tiles.size() * sizeof(StagedTile), hipMemcpyHostToDevice, stream));
@@ -392,21 +481,53 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
         FA_HIP(hipGetLastError());
         FA_HIP(hipMemcpyAsync(tiles.data(), dTiles.get(), tiles.size() * sizeof(StagedTile), hipMemcpyDeviceToHost, stream));
         FA_HIP(hipStreamSynchronize(stream));
-        // tile rows with a tile that does not fit (too many chunks for the slot, too many source rows) are narrowed and
-        // scanned again
-        std::vector<char> narrowed(nBands, 0);
         bool again = false;
-        for (size_t i = 0; i < tiles.size(); ++i)
-            if (tiles[i].nChunks == 0xFFFFFFFFu && !narrowed[bandOf[i]]) {
-                uint32_t& w = bandW[bandOf[i]];
-                if (w <= step) return false;  // not even the narrowest tile fits: positions without spatial coherence
-                w -= step;
-                narrowed[bandOf[i]] = 1;
-                again = true;
+        size_t i = 0;
+        for (uint32_t b = 0; b < nBands; ++b) {
+            const size_t n = rows[b].size();
+            size_t failed = 0;
+            for (size_t k = 0; k < n; ++k) {
+                rows[b][k] = tiles[i + k];
+                if (tiles[i + k].rsv[0] == 0 && tiles[i + k].nChunks == 0xFFFFFFFFu) ++failed;
             }
+            i += n;
+            if (failed == 0) continue;
+            again = true;
+            if (2 * failed > n && rowW[b] > step) {  // the whole row is too heavy: narrower tiles throughout
+                rowW[b] -= step;
+                rows[b].clear();
+                uniform_row(b, rowW[b], rows[b]);
+                continue;
+            }
+            std::vector<StagedTile> next;
+            for (const StagedTile& t : rows[b]) {
+                if (t.rsv[0] != 0 || t.nChunks != 0xFFFFFFFFu) { next.push_back(t); continue; }
+                if (t.w <= step) {  // cannot be split any further
+                    StagedTile g = t;
+                    g.nChunks = 0;
+                    g.rsv[0] = 1;
+                    next.push_back(g);
+                    continue;
+                }
+                StagedTile l = t, r = t;
+                l.w = (t.w / 2 + step - 1) / step * step;
+                r.x0 = t.x0 + l.w;
+                r.w = t.w - l.w;
+                l.nChunks = r.nChunks = 0;
+                next.push_back(l);
+                next.push_back(r);
+            }
+            rows[b].swap(next);
+        }
         if (!again) break;
         if (pass > 64) return false;
     }
+    size_t gatherCells = 0, liveCells = 0;
+    for (const StagedTile& t : tiles) {
+        if (t.rsv[0] != 0) gatherCells += t.w;
+        if (t.rsv[0] != 0 || t.nChunks != 0) liveCells += t.w;
+    }
+    if (gatherCells * 8 > liveCells) return false;  // positions without spatial coherence: the gather kernels serve them better
     size_t total = 0;
     for (auto& t : tiles) {
         FA_REQUIRE(total <= 0xFFFFFFFFu, "staged plan: too many chunks");
@@ -461,7 +582,8 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
 bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
 {
     if (plan.outX * plan.outY == 0) return false;
-    const bool cubic = plan.kind == PlanKind::Bicubic;
+    // the float form of the bicubic stencil is as light as the bilinear one: it takes the bilinear shapes
+    const bool cubic = plan.kind == PlanKind::Bicubic && !plan.bicubicFast;
     // measured on the benchmark plan (profiles/r02_sweep_*.log): 1024 threads on 512 x 8 tiles for the 1 x 1 and 2 x 2 stencils
     // (one workgroup per CU); the 4 x 4 stencil is arithmetic-bound and prefers 128 x 8 tiles on 512 threads
     const int nt = tuning("STAGE2_NT", cubic ? 512 : 1024);
@@ -499,6 +621,8 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.chunkOff = s.chunkOff.get();
     a.ldsA = s.ldsA.get();
     a.ldsB = s.ldsB.get();
+    a.pos = plan.pos.get();
+    a.inX = (uint32_t)plan.inX;
     a.xf = plan.xf.get();
     a.yf = plan.yf.get();
     a.xfd = plan.xfd.get();
@@ -533,7 +657,10 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     switch (plan.kind) {
     case PlanKind::Nearest: launch_shape<1>(s, a, grid, stream); break;
     case PlanKind::Bilinear: launch_shape<2>(s, a, grid, stream); break;
-    default: launch_shape<4>(s, a, grid, stream); break;
+    default:
+        if (plan.bicubicFast) launch_shape<4, true>(s, a, grid, stream);
+        else launch_shape<4>(s, a, grid, stream);
+        break;
     }
     FA_HIP(hipGetLastError());
 }

@@ -101,6 +101,24 @@ int fimex_amd_regrid_plan_create_device(int funcType,
                                         const double* d_pointsOnXAxis, const double* d_pointsOnYAxis, size_t nPoints,
                                         size_t inX, size_t inY, size_t outX, size_t outY,
                                         void* stream, fimex_amd_regrid_plan** plan);
+/**
+ * The same two constructors with the arithmetic of the bicubic kernel chosen per plan (ignored by every other method):
+ *   FIMEX_AMD_BICUBIC_REFERENCE  the reference's operations in the reference's order -- products and row sums in double, four
+ *                                accumulations into the float result (src/interpolation.c:1005-1019): bit-identical output;
+ *   FIMEX_AMD_BICUBIC_FAST       weights rounded to float, float fused multiply-adds: differs from the reference by less than
+ *                                1e-5 of the largest magnitude in the 4x4 stencil (typically 1e-7), and the launch is bound by
+ *                                memory instead of by FP64 arithmetic.  NaN and out-of-domain behaviour are unchanged.
+ */
+#define FIMEX_AMD_BICUBIC_REFERENCE 0
+#define FIMEX_AMD_BICUBIC_FAST 1
+int fimex_amd_regrid_plan_create_opt(int funcType,
+                                     const double* pointsOnXAxis, const double* pointsOnYAxis, size_t nPoints,
+                                     size_t inX, size_t inY, size_t outX, size_t outY,
+                                     int bicubicArithmetic, fimex_amd_regrid_plan** plan);
+int fimex_amd_regrid_plan_create_device_opt(int funcType,
+                                            const double* d_pointsOnXAxis, const double* d_pointsOnYAxis, size_t nPoints,
+                                            size_t inX, size_t inY, size_t outX, size_t outY,
+                                            int bicubicArithmetic, void* stream, fimex_amd_regrid_plan** plan);
 int fimex_amd_regrid_plan_destroy(fimex_amd_regrid_plan* plan);
 
 typedef struct fimex_amd_plan_info {

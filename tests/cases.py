@@ -55,6 +55,27 @@ def backward_positions(inX, inY, outX, outY, seed, overshoot=2.0, special=True):
     return px, py
 
 
+def coherent_positions(inX, inY, outX, outY, seed, wrap=False, outliers=0, angle=0.12):
+    """Fractional source positions of a target grid that is rotated against the source and lies mostly inside it -- the
+    shape of a real reprojection, which the LDS-staged kernels tile.  wrap: the source is periodic in x and the target
+    straddles its seam (a global longitude axis and a target across the date line: positions jump by inX inside a row);
+    outliers: that many isolated cells get positions elsewhere in the source."""
+    rng = np.random.default_rng(seed)
+    j, i = np.meshgrid(np.arange(outY, dtype=np.float64), np.arange(outX, dtype=np.float64), indexing="ij")
+    sx, sy = (inX - 8.0) / (outX * 1.15), (inY - 8.0) / (outY * 1.15)
+    u, v = i - outX / 2.0, j - outY / 2.0
+    px = inX / 2.0 + sx * (np.cos(angle) * u - np.sin(angle) * v) + 0.3 * np.sin(0.05 * j)
+    py = inY / 2.0 + sy * (np.sin(angle) * u + np.cos(angle) * v) + 0.3 * np.cos(0.04 * i)
+    if wrap:
+        px = np.mod(px + inX * 0.37, inX - 1.0)
+    px, py = px.ravel(), py.ravel()
+    if outliers:
+        idx = rng.choice(px.size, outliers, replace=False)
+        px[idx] = rng.uniform(0, inX - 1, outliers)
+        py[idx] = rng.uniform(0, inY - 1, outliers)
+    return px, py
+
+
 def forward_positions(inX, inY, outX, outY, seed, density=1.0, special=True):
     """Fractional target positions per SOURCE cell.  density > 1: several source cells per target
     cell (long buckets); < 1: sparse buckets with many empty targets.  Part of the source falls outside."""

@@ -787,3 +787,66 @@ def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, 
         torch.cuda.synchronize()
         results.append(out.cpu().numpy().view(dt).reshape(want.shape))
         assert np.array_equal(results[-1].view(np.uint8), want.view(np.uint8)), (staged, fused, np.dtype(dt).name)
+
+
+@pytest.mark.parametrize("shape", [(400, 300, 200, 200), (403, 301, 130, 77), (1200, 900, 600, 500)])
+def test_bicubic_fast_arithmetic_within_the_stated_tolerance(fa, shape):
+    """FIMEX_AMD_BICUBIC_FAST (float fused multiply-adds, include/fimex_amd.h) against the oracle's reference arithmetic
+    (src/interpolation.c:959-1028) on adversarial input: a field that crosses zero everywhere (cancellation in the stencil
+    sums) with magnitudes over six decades.  Tolerance as BASELINE.json states it, 1e-5, relative to the largest magnitude
+    in the cell's 4x4 stencil (a result near zero has no digits to be relative to: the reference's own float accumulation
+    errs by 6e-8 of that magnitude there); NaN positions are identical; the reference arithmetic stays bit-exact."""
+    inX, inY, outX, outY = shape
+    nz = 6
+    px, py = cases.coherent_positions(inX, inY, outX, outY, seed=21, outliers=3)
+    rng = np.random.default_rng(22)
+    f = rng.standard_normal((nz, inY, inX)).astype(np.float32)
+    f *= np.float32(10.0) ** rng.integers(-3, 4, (nz, 1, 1)).astype(np.float32)
+    f[:, ::53, ::47] = np.nan
+    want = oracle.interpolate_values(oracle.BICUBIC, px, py, f, inX, inY, outX, outY)
+    fast = fa.RegridPlan(fa.BICUBIC, px, py, inX, inY, outX, outY, bicubic=fa.BICUBIC_FAST)
+    assert fast.info()["stagedCells"] > 0
+    got = fast.apply_host(f)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    # largest |f| in each output cell's stencil: 4x4 window whose corner is (floor(x) - 1, floor(y) - 1)
+    from numpy.lib.stride_tricks import sliding_window_view
+    x0 = np.floor(px).astype(np.int64) - 1
+    y0 = np.floor(py).astype(np.int64) - 1
+    ok = (x0 >= 0) & (x0 + 3 < inX) & (y0 >= 0) & (y0 + 3 < inY)
+    err_rel = 0.0
+    for z in range(nz):
+        win = sliding_window_view(np.abs(np.nan_to_num(f[z])), (4, 4)).max(axis=(2, 3))
+        mag = np.zeros(px.size, np.float32)
+        mag[ok] = win[y0[ok], x0[ok]]
+        d = np.abs(got[z].ravel().astype(np.float64) - want[z].ravel())
+        fin = np.isfinite(want[z].ravel())
+        assert fin.sum() > 0.5 * ok.sum()
+        assert (d[fin] <= 1e-5 * mag[fin]).all(), float((d[fin] / mag[fin]).max())
+        err_rel = max(err_rel, float((d[fin] / mag[fin]).max()))
+    assert 0 < err_rel < 3e-6, err_rel  # typical: a few 1e-7; 0 would mean the reference kernel ran
+    # the default and the explicit reference arithmetic are the bit-exact kernel
+    ref = fa.RegridPlan(fa.BICUBIC, px, py, inX, inY, outX, outY, bicubic=fa.BICUBIC_REFERENCE).apply_host(f)
+    assert cases.same(ref, want)
+    # other methods ignore the switch
+    lin = fa.RegridPlan(fa.BILINEAR, px, py, inX, inY, outX, outY, bicubic=fa.BICUBIC_FAST).apply_host(f)
+    assert cases.same(lin, oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY))
+    with pytest.raises(fa.FimexAmdError, match="bicubic arithmetic"):
+        fa.RegridPlan(fa.BICUBIC, px, py, inX, inY, outX, outY, bicubic=7)
+
+
+@pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
+@pytest.mark.parametrize("wrap,outliers", [(True, 0), (False, 5), (True, 4)])
+def test_staged_plan_with_a_seam_and_isolated_points(fa, method, wrap, outliers):
+    """A target that straddles the seam of a periodic source (positions jump by the row length inside an output row) and
+    isolated cells that point elsewhere: the tiles that hold them cannot be staged through LDS and read their stencils
+    from memory instead (gather tiles, staged2.hip); every other tile stays staged, the result is the oracle's bit for bit.
+    Odd source width on purpose (row segments aligned per row)."""
+    inX, inY, outX, outY, nz = 1441, 721, 900, 500, 6
+    px, py = cases.coherent_positions(inX, inY, outX, outY, seed=31, wrap=wrap, outliers=outliers)
+    f = cases.field(nz, inY, inX, seed=32)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    assert plan.info()["stagedCells"] > 0, "the plan lost its staged form"
+    got = plan.apply_host(f)
+    want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.isfinite(want).mean() > 0.8

@@ -57,7 +57,7 @@ struct StagedTile {
 };
 struct Staged2Plan {
     bool valid = false;
-    uint32_t nt = 0, per = 0, kmax = 0, tileH = 0, tileWMax = 0, nTiles = 0, gridX = 0, ldsBytes = 0;
+    uint32_t nt = 0, per = 0, kmax = 0, tileH = 0, tileWMax = 0, nTiles = 0, gridX = 0, ldsBytes = 0, depth = 2;
     size_t stagedCells = 0, totalChunks = 0;
     DeviceArray<StagedTile> tiles;
     DeviceArray<uint32_t> order;     // workgroup -> tile, ~0u = none (tile rows dealt to the XCDs in stripes)

@@ -9,17 +9,17 @@
 //   * tiles of one height and VARYING width: an output cell of the benchmark plan covers 1.6 .. 3.3 source columns, so a
 //     uniform tile grid sizes every LDS slot for the worst tile and leaves 40 % of it unused.  Here the plan narrows the
 //     tiles of a tile row until every tile fits the same budget;
-//   * a slice ring whose depth each workgroup derives from its own tile (LDS bytes / slot bytes of this tile, 2 .. maxDepth)
-//     instead of one compile-time depth sized for the largest tile;
+//   * one copy of the slice loop per number of DMA instructions a lane issues per slice (1 .. KMAX, chosen per tile), so that
+//     no instruction is issued for chunks a tile does not have and every s_waitcnt keeps an immediate count;
 //   * the plan stores the source offset of every 16-byte chunk of a tile, so the workgroup prologue is a coalesced load
 //     instead of a binary search per chunk, and row segments start on 16-byte boundaries of the slice for any row length
 //     (inX % 4 != 0 included: a reduced domain, src/CachedInterpolation.cc:159-200, crops to arbitrary widths);
-//   * DMA instructions whose 64 chunks all lie beyond the tile's list are not issued (the wait counts follow at run time);
 //   * tile rows are dealt to the XCDs in stripes (neighbours in x share an L2) through a workgroup -> tile table.
 #include "plan.hpp"
 #include "staged_common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace fimex_amd {
@@ -149,31 +149,15 @@ struct Staged2Args {
     uint32_t nz;
     uint32_t zStart[kMaxZChunks + 1];  // slices [zStart[c], zStart[c + 1]) belong to z chunk c = blockIdx.y
     uint32_t ldsFloats;  // floats of the slice ring
-    uint32_t maxDepth;
     uint32_t flags;      // tuning build only: 1 no source loads, 2 no result stores
 };
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): a jump over the 64 encodings
-__device__ __forceinline__ void wait_vmcnt_dyn(uint32_t n)
-{
-    n = __builtin_amdgcn_readfirstlane(n);
-#define FA_W(k) case k: wait_vmcnt<k>(); break;
-#define FA_W8(k) FA_W(k) FA_W(k + 1) FA_W(k + 2) FA_W(k + 3) FA_W(k + 4) FA_W(k + 5) FA_W(k + 6) FA_W(k + 7)
-    switch (n) {
-        FA_W8(0) FA_W8(8) FA_W8(16) FA_W8(24) FA_W8(32) FA_W8(40) FA_W8(48)
-        FA_W(56) FA_W(57) FA_W(58) FA_W(59) FA_W(60) FA_W(61) FA_W(62)
-    default: wait_vmcnt<63>(); break;
-    }
-#undef FA_W8
-#undef FA_W
-}
 
 // STENCIL: 1 nearest, 2 bilinear, 4 bicubic; NT: threads of the workgroup; PER: outputs per lane (tile = NT * PER outputs);
 // KMAX: most 16-byte chunks a lane stages per slice.
 // FAST (bicubic only): the weights rounded to float and float fused multiply-adds instead of the reference's double products
 // accumulated into a float (interpolation.c:1005-1019) -- not bit-identical, within 1e-5 of the stencil's magnitude (the
 // tolerance BASELINE.json states), chosen per plan (FIMEX_AMD_BICUBIC_FAST).
-template <int STENCIL, int NT, int PER, int KMAX, bool FAST = false>
+template <int STENCIL, int NT, int PER, int KMAX, bool FAST = false, int DEPTH = 2>
 __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -190,36 +174,25 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
     const uint32_t outRecords = (kTuningBuild && (a.flags & 2)) ? 0u : outBytes;
 
     // ---- the staging list and the first DMAs come before everything else: the per-output plan below loads while they fly
-    // per-lane staging list: chunk c = threadIdx.x + j * NT of the tile's list; a wave skips the instructions whose 64
-    // chunks all lie beyond the list (un = instructions this wave issues per slice)
+    // per-lane staging list: chunk c = threadIdx.x + j * NT of the tile's list, un = DMA instructions per lane and slice
     const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
     uint32_t gOff[KMAX];
-    uint32_t un = 0;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
         const uint32_t c = threadIdx.x + j * NT;
         gOff[j] = (c < T.nChunks) ? a.chunkOff[T.chunkBase + c] * 4u : 0xFFFFFFFFu;  // ~0u: dropped by the bounds check (zeros)
-        if (waveChunk + j * NT < T.nChunks) un = j + 1;
     }
-    un = __builtin_amdgcn_readfirstlane(un);
-    const uint32_t slotFloats = ((T.nChunks + 63u) & ~63u) * 4u + 4u;
-    uint32_t depth = a.ldsFloats / slotFloats;  // >= 2 by construction of the plan
-    depth = min(depth, a.maxDepth);
-    depth = min(depth, nzl + 1);
-    if (depth < 2) depth = 2;
+    const uint32_t un = (T.nChunks + NT - 1) / NT;
+    const uint32_t slotFloats = (a.ldsFloats / DEPTH) & ~3u;  // DEPTH slots, each holds the largest tile of the plan
     const uint32_t inRecords = (kTuningBuild && (a.flags & 1)) ? 0u : a.inBytes;
 
-    auto dma = [&](uint32_t slot, uint32_t z) {
-        const rsrc_t rs = make_rsrc(inBase + (size_t)z * a.inBytes, inRecords);
-        float* dst = smem + slot * slotFloats;
+    // prologue: DEPTH - 1 slices in flight (issued here, before the per-output plan is loaded)
+    for (uint32_t i = 0; i + 1 < (uint32_t)DEPTH && i < nzl; ++i) {
+        const rsrc_t rs = make_rsrc(inBase + (size_t)(z0 + i) * a.inBytes, inRecords);
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
-            if ((uint32_t)j < un) dma16(rs, dst + (waveChunk + j * NT) * 4, gOff[j]);
-    };
-
-    // prologue: depth - 1 slices in flight, the first one landed
-    const uint32_t pre = min(depth - 1, nzl);
-    for (uint32_t i = 0; i < pre; ++i) dma(i, z0 + i);
+            if ((uint32_t)j < un) dma16(rs, smem + i * slotFloats + (waveChunk + j * NT) * 4, gOff[j]);
+    }
     // ---- per-lane plan: outputs e = threadIdx.x + k * NT of the tile (a wave covers 64 consecutive cells of one row)
     uint32_t cellOff[PER];
     uint32_t row[PER][STENCIL];
@@ -325,101 +298,121 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
         return;
     }
 
-    wait_vmcnt_dyn((pre - 1) * un);
+    // Main loop with the number of DMA instructions per slice as a compile-time constant (one copy of the loop per value), so
+    // that every wait is an immediate: results come back in issue order, and behind the DMA of slice i + 1 the DMAs of the
+    // slices i + 2 .. i + DEPTH - 1 and the stores of the last DEPTH - 1 iterations may stay in flight.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first DEPTH - 1 slices (a workgroup's first wait only)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    uint32_t slot = 0;
-    for (uint32_t i = 0; i < nzl; ++i) {
-        const uint32_t z = z0 + i;
-        if (i + depth - 1 < nzl) {  // into the slot slice i - 1 has left
-            uint32_t s = slot + depth - 1;
-            if (s >= depth) s -= depth;
-            dma(s, z + depth - 1);
-        }
-        const char* curb = reinterpret_cast<const char*>(smem + slot * slotFloats);
-        const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
-        if constexpr (STENCIL == 1) {
-            float v[PER];
+    auto run = [&](auto unTag) {
+        constexpr int UN = decltype(unTag)::value;
+        uint32_t slot = 0;
+        for (uint32_t i = 0; i < nzl; ++i) {
+            const uint32_t z = z0 + i;
+            const bool more = i + DEPTH - 1 < nzl;
+            if (more) {  // into the slot slice i - 1 has left
+                const uint32_t sl = (slot + DEPTH - 1 >= (uint32_t)DEPTH) ? slot - 1 : slot + DEPTH - 1;
+                const rsrc_t rs = make_rsrc(inBase + (size_t)(z + DEPTH - 1) * a.inBytes, inRecords);
+                float* dst = smem + sl * slotFloats;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
-#pragma unroll
-            for (int k = 0; k < PER; ++k)  // src/interpolation.c:869-876
-                __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);
-        } else if constexpr (STENCIL == 2) {
-            float s00[PER], s01[PER], s10[PER], s11[PER];
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {  // all stencil reads first: 2 x ds_read2_b32 per output, no waits in between
-                const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
-                const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
-                s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
+                for (int j = 0; j < UN; ++j) dma16(rs, dst + (waveChunk + j * NT) * 4, gOff[j]);
             }
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
-                // interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911)
-                const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];
-                const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];
-                const float inter = (1.f - yf[k]) * top + yf[k] * bot;
-                const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
-                float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
-                r = undef[k] ? undefined_f() : r;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                float f[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f[r][j] = *reinterpret_cast<const float*>(curb + row[k][r] + 4 * j);
+            const char* curb = reinterpret_cast<const char*>(smem + slot * slotFloats);
+            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+            if constexpr (STENCIL == 1) {
+                float v[PER];
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
+    #pragma unroll
+                for (int k = 0; k < PER; ++k)  // src/interpolation.c:869-876
+                    __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);
+            } else if constexpr (STENCIL == 2) {
+                float s00[PER], s01[PER], s10[PER], s11[PER];
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) {  // all stencil reads first: 2 x ds_read2_b32 per output, no waits in between
+                    const float* pa = reinterpret_cast<const float*>(curb + row[k][0]);
+                    const float* pb = reinterpret_cast<const float*>(curb + row[k][1]);
+                    s00[k] = pa[0]; s01[k] = pa[1]; s10[k] = pb[0]; s11[k] = pb[1];
                 }
-                float acc = 0;  // interpolation.c:1005: accumulates into the float output
-                if constexpr (FAST) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float xmf = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) xmf = __builtin_fmaf(XMf[k][j], f[r][j], xmf);
-                        acc = __builtin_fmaf(xmf, MYf[k][r], acc);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        double xmf = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[r][j];  // :1015
-                        acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
-                    }
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
+                    // interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911)
+                    const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];
+                    const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];
+                    const float inter = (1.f - yf[k]) * top + yf[k] * bot;
+                    const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
+                    float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
+                    r = undef[k] ? undefined_f() : r;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(undef[k] ? undefined_f() : acc), ro, cellOff[k], 0, 2);
+            } else {
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    float f[4][4];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) f[r][j] = *reinterpret_cast<const float*>(curb + row[k][r] + 4 * j);
+                    }
+                    float acc = 0;  // interpolation.c:1005: accumulates into the float output
+                    if constexpr (FAST) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float xmf = 0;
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) xmf = __builtin_fmaf(XMf[k][j], f[r][j], xmf);
+                            acc = __builtin_fmaf(xmf, MYf[k][r], acc);
+                        }
+                    } else {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double xmf = 0;
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) xmf += XM[k][j] * (double)f[r][j];  // :1015
+                            acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(undef[k] ? undefined_f() : acc), ro, cellOff[k], 0, 2);
+                }
             }
+            if (more) wait_vmcnt<(DEPTH - 2) * UN + (DEPTH - 1) * PER>();
+            else wait_vmcnt<PER>();  // the tail of the z chunk: everything but this slice's stores
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            slot = (slot + 1 == (uint32_t)DEPTH) ? 0 : slot + 1;
         }
-        if (i + 1 < nzl) {
-            // Slice i + 1 must have landed.  Results come back in issue order; issued after its DMA and allowed to stay in
-            // flight: the DMAs of the slices behind it and the stores of the iterations since.
-            const uint32_t lastIssued = min(i + depth - 1, nzl - 1);
-            const uint32_t youngerDma = lastIssued - (i + 1);
-            const uint32_t youngerStores = min(depth - 1, i + 1);
-            wait_vmcnt_dyn(min(63u, youngerDma * un + youngerStores * PER));
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        slot = (slot + 1 == depth) ? 0 : slot + 1;
+    };
+    static_assert(KMAX <= 8, "one copy of the loop per DMA count");
+    switch (un) {
+    case 1: run(std::integral_constant<int, 1>()); break;
+    case 2: run(std::integral_constant<int, KMAX >= 2 ? 2 : 1>()); break;
+    case 3: run(std::integral_constant<int, KMAX >= 3 ? 3 : 1>()); break;
+    case 4: run(std::integral_constant<int, KMAX >= 4 ? 4 : 1>()); break;
+    case 5: run(std::integral_constant<int, KMAX >= 5 ? 5 : 1>()); break;
+    case 6: run(std::integral_constant<int, KMAX >= 6 ? 6 : 1>()); break;
+    case 7: run(std::integral_constant<int, KMAX >= 7 ? 7 : 1>()); break;
+    default: run(std::integral_constant<int, KMAX >= 8 ? 8 : 1>()); break;
     }
 }
 
 struct Shape2 {
     int nt, per, kmax;
+    uint32_t depth;
     uint32_t tileW, tileH;  // widest tile
     uint32_t ldsBytes;
 };
 
 template <int STENCIL, int NT, int PER, int KMAX, bool FAST = false>
-void launch_one(const Staged2Args& a, dim3 grid, size_t ldsBytes, hipStream_t stream)
+void launch_one(const Staged2Args& a, dim3 grid, size_t ldsBytes, uint32_t depth, hipStream_t stream)
 {
-    allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply2<STENCIL, NT, PER, KMAX, FAST>), ldsBytes);
-    staged_apply2<STENCIL, NT, PER, KMAX, FAST><<<grid, NT, ldsBytes, stream>>>(a);
+    if (depth == 3) {
+        allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply2<STENCIL, NT, PER, KMAX, FAST, 3>), ldsBytes);
+        staged_apply2<STENCIL, NT, PER, KMAX, FAST, 3><<<grid, NT, ldsBytes, stream>>>(a);
+    } else {
+        allow_dynamic_lds(reinterpret_cast<const void*>(&staged_apply2<STENCIL, NT, PER, KMAX, FAST, 2>), ldsBytes);
+        staged_apply2<STENCIL, NT, PER, KMAX, FAST, 2><<<grid, NT, ldsBytes, stream>>>(a);
+    }
 }
 
 template <int STENCIL, bool FAST = false>
@@ -427,12 +420,12 @@ void launch_shape(const Staged2Plan& s, const Staged2Args& a, dim3 grid, hipStre
 {
     const uint32_t key = s.nt * 10000 + s.per * 100 + s.kmax;
     switch (key) {
-    case 2560406: launch_one<STENCIL, 256, 4, 6, FAST>(a, grid, s.ldsBytes, stream); break;
-    case 5120406: launch_one<STENCIL, 512, 4, 6, FAST>(a, grid, s.ldsBytes, stream); break;
-    case 10240405: launch_one<STENCIL, 1024, 4, 5, FAST>(a, grid, s.ldsBytes, stream); break;
-    case 5120203: launch_one<STENCIL, 512, 2, 3, FAST>(a, grid, s.ldsBytes, stream); break;
-    case 10240203: launch_one<STENCIL, 1024, 2, 3, FAST>(a, grid, s.ldsBytes, stream); break;
-    case 2560204: launch_one<STENCIL, 256, 2, 4, FAST>(a, grid, s.ldsBytes, stream); break;
+    case 2560406: launch_one<STENCIL, 256, 4, 6, FAST>(a, grid, s.ldsBytes, s.depth, stream); break;
+    case 5120406: launch_one<STENCIL, 512, 4, 6, FAST>(a, grid, s.ldsBytes, s.depth, stream); break;
+    case 10240405: launch_one<STENCIL, 1024, 4, 5, FAST>(a, grid, s.ldsBytes, s.depth, stream); break;
+    case 5120203: launch_one<STENCIL, 512, 2, 3, FAST>(a, grid, s.ldsBytes, s.depth, stream); break;
+    case 10240203: launch_one<STENCIL, 1024, 2, 3, FAST>(a, grid, s.ldsBytes, s.depth, stream); break;
+    case 2560204: launch_one<STENCIL, 256, 2, 4, FAST>(a, grid, s.ldsBytes, s.depth, stream); break;
     default: throw Error("staged2: unexpected workgroup shape");
     }
 }
@@ -443,8 +436,8 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
     const uint32_t outX = (uint32_t)plan.outX, outY = (uint32_t)plan.outY;
     const uint32_t tileH = sh.tileH;
     const uint32_t nBands = (uint32_t)ceil_div(outY, tileH);
-    // the ring holds at least two slots of the largest tile; a slot is its chunks rounded up to whole wave instructions
-    uint32_t cap = (sh.ldsBytes / 2 - 16) / 16;
+    // the ring holds `depth` slots, each large enough for any tile (chunks rounded up to whole wave instructions)
+    uint32_t cap = (sh.ldsBytes / sh.depth - 16) / 16;
     cap = std::min<uint32_t>(cap & ~63u, (uint32_t)sh.kmax * sh.nt);
     cap = std::min<uint32_t>(cap, 16383u);  // 16-bit LDS offsets in floats
     const uint32_t step = sh.tileW >= 128 ? 64u : 32u;  // tile widths are multiples of this (a wave stores 64 consecutive cells)
@@ -569,6 +562,7 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
     s.nTiles = (uint32_t)tiles.size();
     s.gridX = (uint32_t)order.size();
     s.ldsBytes = sh.ldsBytes;
+    s.depth = sh.depth;
     s.totalChunks = total;
     s.stagedCells = total * 4;
     s.valid = true;
@@ -585,8 +579,9 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     // the float form of the bicubic stencil is as light as the bilinear one: it takes the bilinear shapes
     const bool cubic = plan.kind == PlanKind::Bicubic && !plan.bicubicFast;
     // measured on the benchmark plan (profiles/r02_sweep_*.log): 1024 threads on 512 x 8 tiles for the 1 x 1 and 2 x 2 stencils
-    // (one workgroup per CU); the 4 x 4 stencil is arithmetic-bound and prefers 128 x 8 tiles on 512 threads
-    const int nt = tuning("STAGE2_NT", cubic ? 512 : 1024);
+    // (one workgroup per CU); the 4 x 4 stencil in the reference's arithmetic is FP64-bound and prefers 128 x 8 tiles on 512
+    // threads, in float arithmetic 256 x 8 tiles on 512 threads (its halo makes taller or wider tiles stage more)
+    const int nt = tuning("STAGE2_NT", (cubic || plan.bicubicFast) ? 512 : 1024);
     if (!(nt == 256 || nt == 512 || nt == 1024)) return false;
     Shape2 sh{};
     sh.nt = nt;
@@ -601,7 +596,10 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     const int ldsDefault = nt == 256 ? 52 : (nt == 512 ? 79 : 159);
     sh.ldsBytes = (uint32_t)tuning("STAGE2_LDS_KB", ldsDefault) * 1024u;
     if (sh.ldsBytes > 160u * 1024u - 64u) sh.ldsBytes = 160u * 1024u - 64u;
-    const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", 1));
+    sh.depth = tuning("STAGE2_DEPTH", 2) == 3 ? 3u : 2u;  // slices of the ring: one or two in flight while one is interpolated
+    // stripes of 8 tile rows per XCD: the bilinear launch fetches 10.2 instead of 11.1 GB (vertical neighbours meet in one L2) at
+    // the same or a slightly shorter time; the 1 x 1 stencil shares nothing vertically and runs 3 % faster with single rows
+    const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", plan.kind == PlanKind::Bilinear ? 8 : 1));
     switch (plan.kind) {
     case PlanKind::Nearest: return build_shape<1>(plan, d_px, d_py, stream, sh, stripe);
     case PlanKind::Bilinear: return build_shape<2>(plan, d_px, d_py, stream, sh, stripe);
@@ -651,7 +649,6 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     }
     a.zStart[nChunks] = (uint32_t)nz;
     a.ldsFloats = s.ldsBytes / 4;
-    a.maxDepth = (uint32_t)std::max(2, tuning("STAGE2_DEPTH", 4));
     a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0);
     const dim3 grid(s.gridX, nChunks, 1);
     switch (plan.kind) {

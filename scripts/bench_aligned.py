@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from fimex_amd import capi as fa
 import workloads, bench
+fa.use_tuning_build(True)  # FIMEX_AMD_<NAME> switches select the kernel shape
 fa.load(); fa.set_device(0)
 st = torch.cuda.current_stream().cuda_stream
 wl = workloads.BilinearRotatedPole()

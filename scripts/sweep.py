@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--method", default="bilinear")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--bicubic-fast", action="store_true")
     ap.add_argument("variants", nargs="*", default=[""])
     a = ap.parse_args()
     import torch
@@ -38,7 +39,7 @@ def main():
             os.environ["FIMEX_AMD_" + k] = val
     for v in a.variants:  # tile shape knobs (STAGE_TW, STAGE_PER, STAGE_K) act when the plan is built
         setenv(v)
-        plans[v] = bench.build_plan(fa, torch, wl, method, stream)[0]
+        plans[v] = bench.build_plan(fa, torch, wl, method, stream, bicubic=fa.BICUBIC_FAST if a.bicubic_fast else None)[0]
         info = plans[v].info()
         print("plan %-30s tile %sx%s staged cells %s" % (v or "(defaults)", info.get("tileW"), info.get("tileH"), info.get("stagedCells")), flush=True)
     times = {v: [] for v in a.variants}

@@ -846,6 +846,11 @@ struct Fill2dV2Args {
     float relaxCrit, corrEff;
     unsigned long long maxLoop;
     int sumAlgo;
+    unsigned int* error;      // one word per launch: set by a wait that gave up (see MultiWg)
+    // several workgroups per slice (fill2d_kernel_v3): per slice [0] barrier counter, [1..2] "not converged" by parity of the
+    // check, [4 .. 4 + bands) progress words of the bands whose hand-off crosses workgroups
+    unsigned int* sync;
+    uint32_t syncStride, groups, nz;
 };
 
 // Flags of the LDS hand-off.  The LDS executes one wave's operations in issue order and is coherent within the CU, so a
@@ -883,6 +888,66 @@ __device__ __forceinline__ float lane_value(float v, int idx)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), idx));
 }
 
+// ---- several workgroups per slice (small batches): the bands of one slice are dealt to G workgroups, W = waves per workgroup
+// at a time (bands 0 .. W-1 to workgroup 0, W .. 2W-1 to workgroup 1, ...), so that a batch of 16 slices uses 96 CUs instead of
+// 16.  Inside a workgroup nothing changes; the hand-off of every W-th band boundary, which already went through global memory,
+// now crosses workgroups: the producer's stores of that band are write-through (sc0 sc1), it publishes its progress in a
+// global word after s_waitcnt vmcnt(0) (relaxed agent-scope store = sc1), the consumer polls that word and reads the row
+// above with sc0 sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility: every store and every load of the handed-off
+// bytes bypasses the non-coherent caches).  The sweeps of the workgroups of a slice are separated by a barrier on a global
+// counter with agent-scope release / acquire, which makes everything else (the row below a band, the border columns) visible.
+// Every wait is bounded: a spin that exceeds its cap sets the launch's error word, every other wait then falls through, the
+// kernel ends and the host call fails with a message -- a wrong counter cannot hang the GPU.
+struct MultiWg {
+    uint32_t g, G;            // this workgroup and the number of workgroups of its slice (1: the single-workgroup kernels)
+    unsigned int* flags;      // [bands] progress of the bands whose hand-off crosses workgroups: columns final + 1
+    unsigned int* error;      // one word per launch
+};
+constexpr unsigned int kSpinCapLds = 1u << 24;     // ~1 s of polling LDS
+constexpr unsigned int kSpinCapGlobal = 1u << 21;  // ~1 s of polling memory
+
+__device__ __forceinline__ bool launch_failed(const unsigned int* error)
+{
+    return __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void fail_launch(unsigned int* error, unsigned int code)
+{
+    __hip_atomic_store(error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits until the LDS word reaches `need`; false: gave up (cap or another wave's failure)
+__device__ __forceinline__ bool wait_lds_at_least(const unsigned int* flag, unsigned int need, unsigned int* error)
+{
+    for (unsigned int it = 0;; ++it) {
+        asm volatile("" ::: "memory");
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) { asm volatile("" ::: "memory"); return true; }
+        __builtin_amdgcn_s_sleep(1);
+        if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(error))) { fail_launch(error, 1); return false; }
+    }
+}
+__device__ __forceinline__ bool wait_global_at_least(const unsigned int* flag, unsigned int need, unsigned int* error)
+{
+    for (unsigned int it = 0;; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { asm volatile("" ::: "memory"); return true; }
+        __builtin_amdgcn_s_sleep(2);
+        if ((it & 0xFF) == 0xFF && (it >= kSpinCapGlobal || launch_failed(error))) { fail_launch(error, 2); return false; }
+    }
+}
+// barrier of the G workgroups of one slice on a monotone global counter (instance k waits for k * G arrivals)
+__device__ __forceinline__ void slice_barrier(unsigned int* counter, unsigned int target, unsigned int* error)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_global_at_least(counter, target, error);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 constexpr int kHandW = 192;  // columns of a band's last row kept in LDS for the band below
 
 // LDS hand-off between consecutive bands: the wave of band b publishes its last row's new values in
@@ -908,9 +973,9 @@ __device__ __forceinline__ float sor_error(float sum, float center) { return __b
 // chunks: loads issued there are consumed one event later, stores are never waited for (the sweep ends with a
 // workgroup barrier); the 16 steps in between run on registers and LDS.
 // CHECK: a sweep that also tests convergence (every tenth, :1339-1360); the other nine carry no trace of the test
-template <int CH, int WAVES, bool CHECK>
+template <int CH, int WAVES, bool CHECK, bool MULTI = false>
 __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ maskS, float* ring, Handoff hand, uint32_t b,
-                            uint32_t nx, uint32_t ny, uint32_t mws, float wInt, float wZero, float crtest, int& bad)
+                            uint32_t nx, uint32_t ny, uint32_t mws, float wInt, float wZero, float crtest, int& bad, MultiWg mg)
 {
     FILL_GEOMETRY(CH, WAVES);
     constexpr bool check = CHECK;
@@ -934,6 +999,14 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     // (loads return 0, stores are dropped), so every memory instruction is issued unconditionally
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f + (size_t)(y0 - 1) * nx, 0, (nrow + 2) * nx * 4u, 0x00020000);
     const uint32_t kOob = 0xFFFFFFFFu;
+    // Every W-th boundary (band W-1 -> W, 2W-1 -> 2W, ...) goes through global memory: in one workgroup the wave of band b + 1
+    // is still busy with band b + 1 - W there (a bounded LDS window would close a cycle of waiting waves on wide grids), with
+    // several workgroups per slice (MULTI) band b + 1 belongs to the next workgroup.  The producer's flush already writes the
+    // row; it only has to publish how far its stores have completed.
+    const bool hasBelow = y0 + nrow < ny - 1;
+    const bool outGlobal = hasBelow && (b % kV2Waves) == kV2Waves - 1;
+    const bool inGlobal = b > 0 && (b % kV2Waves) == 0;
+    const bool writeThrough = MULTI && outGlobal;  // the band below reads these rows on another CU, maybe another XCD
 
     // chunk c = skewed columns [c*kCh, c*kCh + kCh) of all 64 rows; lane -> (row kRowsPerIt*it + lane/kCh, column lane%kCh)
     const uint32_t crow = lane / kCh, ccol = lane % kCh;
@@ -977,43 +1050,45 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         if (interior(c)) {
             const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
-            for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
+            for (uint32_t it = 0; it < (uint32_t)kCh; ++it) {
+                if (writeThrough) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 17);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
+            }
             return;
         }
 #pragma unroll
-        for (uint32_t it = 0; it < (uint32_t)kCh; ++it)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
+        for (uint32_t it = 0; it < (uint32_t)kCh; ++it) {
+            if (writeThrough) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 17);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
+        }
     };
     auto load_block = [&](uint32_t rowInBuf, uint32_t k) {  // 64 columns of the row above (0) / below (nrow + 1)
         const uint32_t col = 64 * k + lane;
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col <= nx - 1 ? (rowInBuf * nx + col) * 4u : kOob, 0, 0));
+        const uint32_t off = col <= nx - 1 ? (rowInBuf * nx + col) * 4u : kOob;
+        // the row above a band whose predecessor runs in another workgroup: written during this sweep, read past L1 and L2
+        if (MULTI && inGlobal && rowInBuf == 0) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 17));
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
     };
 
     // hand-off slots: mine (towards band b + 1) and the one of band b - 1
-    const uint32_t slotOut = (b % kV2Waves) * 2 + ((b / kV2Waves) & 1);
-    const uint32_t slotIn = ((b - 1) % kV2Waves) * 2 + (((b - 1) / kV2Waves) & 1);  // unused for b == 0
+    const uint32_t round = kV2Waves * (MULTI ? mg.G : 1u);  // bands between two bands of one wave
+    const uint32_t slotOut = (b % kV2Waves) * 2 + ((b / round) & 1);
+    const uint32_t slotIn = ((b - 1) % kV2Waves) * 2 + (((b - 1) / round) & 1);  // unused for b == 0
     float* handOut = hand.data + slotOut * kHandW;
     const float* handIn = hand.data + slotIn * kHandW;
     if (lane == 0) {
         __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&hand.consumed[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // Every 16th boundary (band 15 -> 16, 31 -> 32, ...) goes through global memory instead: the wave of band b + 1 is
-    // still busy with band b - 15 there, so a bounded LDS window would close a cycle of waiting waves on wide grids.
-    // The producer's flush already writes the row; it only has to publish how far its stores have completed.
-    const bool hasBelow = y0 + nrow < ny - 1;
-    const bool outGlobal = hasBelow && (b % kV2Waves) == kV2Waves - 1;
-    const bool inGlobal = b > 0 && (b % kV2Waves) == 0;
-    auto wait_above = [&](uint32_t k) {
-        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
-        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
+    auto wait_above = [&](uint32_t k) {  // the stores of band b - 1 up to block k of its last row have completed
+        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], min(64 * k + 64, C + 1) + 1, mg.error); return; }
+        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), mg.error);
     };
     // block k (columns 64k .. 64k+63) of the row above from the hand-off of band b - 1
     auto take_above = [&](uint32_t k) -> float {
         const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
         // a larger band tag means the producer has finished band b - 1 long ago (its data stay in the other parity slot)
-        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
+        wait_lds_at_least(&hand.produced[slotIn], need, mg.error);
         const float v = handIn[(64 * k + lane) % kHandW];
         if (lane == 0)
             lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64));
@@ -1049,8 +1124,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             // ---- event at the start of chunk c
             if (outGlobal && xpc > L) {  // stores of the previous event (chunk c - 2) have landed: columns < 16 (c - 1) - L of the last row
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0 && xpc - kCh > L)
-                    lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L));
+                if (lane == 0 && xpc - kCh > L) {
+                    if (MULTI) __hip_atomic_store(&mg.flags[b], xpc - kCh - L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L));
+                }
             }
             // Order matters: vector-memory results come back in issue order, so waiting for a load also waits for every
             // load issued before it.  The small loads (mask word, 64-column blocks of the rows above / below) go first,
@@ -1083,10 +1160,11 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                     lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
                 if (hasBelow) {
                     const unsigned int limit = xpc + kCh - L;  // columns < limit are written during this chunk
-                    while (true) {
+                    for (unsigned int it = 0;; ++it) {
                         const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
                         if (limit <= (cns & 0x7FFFFu) + kHandW) break;
                         __builtin_amdgcn_s_sleep(1);
+                        if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(mg.error))) { fail_launch(mg.error, 3); break; }
                     }
                 }
             }
@@ -1201,7 +1279,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     }
     flush_chunk(nChunks - 1);
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
+    if (lane == 0) {
+        if (MULTI && outGlobal) __hip_atomic_store(&mg.flags[b], C + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
+    }
 }
 
 template <int CH, int WAVES>
@@ -1234,14 +1315,15 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
     const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
     float* ring = rings + wave * (kWave + 1) * kPitch;
+    const MultiWg single{0u, 1u, nullptr, a.error};
     for (unsigned long long n = 0; n < a.maxLoop; ++n) {
         const bool check = (n < (a.maxLoop - 5)) && (n % 10 == 0);
         int bad = 0;
         if (threadIdx.x < kV2Waves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
         __syncthreads();
         for (uint32_t b = wave; b < nBands; b += kV2Waves)
-            if (check) fill2d_band<CH, WAVES, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad);
-            else fill2d_band<CH, WAVES, false>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad);
+            if (check) fill2d_band<CH, WAVES, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad, single);
+            else fill2d_band<CH, WAVES, false>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad, single);
         if (check) {
             if (!__syncthreads_or(bad)) return;  // converged (:1355-1359), before the border pass
         } else {
@@ -1261,6 +1343,85 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
             f[bo] += (f[bo - nx] - f[bo]) * wb;
         }
         __syncthreads();
+    }
+}
+
+// The same sweeps with the bands of a slice dealt to a.groups workgroups (MultiWg above).  Workgroup i serves slice
+// (i % 8) + 8 * (i / (8 * groups)) as its member (i / 8) % groups: the workgroups of a slice have the same i % 8, which is how
+// workgroups are dealt to the XCDs today (a speed bonus for the hand-off, not a condition: the write-through stores and the
+// loads past the caches hold on any placement).  Launched cooperatively: the workgroups of a slice wait for each other.
+template <int CH, int WAVES>
+__global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v3(Fill2dV2Args a)
+{
+    FILL_GEOMETRY(CH, WAVES);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rings = smem;
+    Handoff hand;
+    hand.data = smem + kV2Waves * (kWave + 1) * kPitch;
+    hand.produced = reinterpret_cast<unsigned int*>(hand.data + kV2Waves * 2 * kHandW);
+    hand.consumed = hand.produced + kV2Waves * 2;
+    const uint32_t G = a.groups;
+    const uint32_t slice = (blockIdx.x % kXcds) + kXcds * (blockIdx.x / (kXcds * G));
+    const uint32_t g = (blockIdx.x / kXcds) % G;
+    if (slice >= a.nz) return;
+    const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
+    const size_t total = (size_t)nx * ny;
+    float* f = a.field + (size_t)slice * total;
+    uint32_t* maskS = a.maskS + (size_t)slice * ny * mws;
+    unsigned char* mbTop = a.mbRows + (size_t)slice * 2 * nx;
+    unsigned char* mbBot = mbTop + nx;
+    unsigned char* mbLeft = a.mbCols + (size_t)slice * 2 * ny;
+    unsigned char* mbRight = mbLeft + ny;
+    SliceStats* st = a.stats + slice;
+    unsigned int* sync = a.sync + (size_t)slice * a.syncStride;
+    const MultiWg mg{g, G, sync + 4, a.error};
+    const uint32_t wave = threadIdx.x / kWave;
+    if (st->skip) return;  // :1266-1269 (the same for every workgroup of the slice)
+    const double crit = st->meanAbsDev;
+    const float wInt = 1.f * a.corrEff, wZero = 0.f * a.corrEff;  // :1311-1315
+    const float crtest = (float)(crit * a.corrEff);
+    const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
+    const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
+    float* ring = rings + wave * (kWave + 1) * kPitch;
+    unsigned int barriers = 0, checks = 0;
+    for (unsigned long long n = 0; n < a.maxLoop; ++n) {
+        const bool check = (n < (a.maxLoop - 5)) && (n % 10 == 0);
+        int bad = 0;
+        if (threadIdx.x < kV2Waves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
+        __syncthreads();
+        for (uint32_t b = g * kV2Waves + wave; b < nBands; b += G * kV2Waves)
+            if (check) fill2d_band<CH, WAVES, true, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad, mg);
+            else fill2d_band<CH, WAVES, false, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad, mg);
+        unsigned int* notConverged = sync + 1 + (checks & 1);
+        if (check) {
+            if (__syncthreads_or(bad) && threadIdx.x == 0) __hip_atomic_fetch_or(notConverged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        slice_barrier(sync, ++barriers * G, a.error);
+        if (launch_failed(a.error)) return;
+        if (check) {
+            if (__hip_atomic_load(notConverged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // converged (:1355-1359)
+            ++checks;
+            if (g == 0 && threadIdx.x == 0)  // the word of the check after next (read last ten sweeps ago)
+                __hip_atomic_store(sync + 1 + (checks & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // progress words of this workgroup's outgoing hand-offs: back to "nothing" for the next sweep
+        for (uint32_t b = g * kV2Waves + kV2Waves - 1 + threadIdx.x * G * kV2Waves; b < nBands; b += kV2Threads * G * kV2Waves)
+            __hip_atomic_store(mg.flags + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t y = 1 + g * kV2Threads + threadIdx.x; y < nym1; y += G * kV2Threads) {  // :1363-1366
+            const size_t r = (size_t)y * nx;
+            const float wl = mbLeft[y] ? 1.f : 0.f, wr = mbRight[y] ? 1.f : 0.f;
+            f[r] += (f[r + 1] - f[r]) * wl;
+            f[r + nxm1] += (f[r + nx - 2] - f[r + nxm1]) * wr;
+        }
+        slice_barrier(sync, ++barriers * G, a.error);
+        for (uint32_t x = g * kV2Threads + threadIdx.x; x < nx; x += G * kV2Threads) {  // :1367-1370
+            const size_t bo = (size_t)nym1 * nx + x;
+            const float wt = mbTop[x] ? 1.f : 0.f, wb = mbBot[x] ? 1.f : 0.f;
+            f[x] += (f[nx + x] - f[x]) * wt;
+            f[bo] += (f[bo - nx] - f[bo]) * wb;
+        }
+        slice_barrier(sync, ++barriers * G, a.error);
+        if (launch_failed(a.error)) return;
     }
 }
 
@@ -1413,6 +1574,7 @@ struct CreepV2Args {
     int setWeight;     // >= 0
     int sumAlgo;
     int skipIdle;
+    unsigned int* error;  // one word per launch: set by a wait that gave up (see MultiWg)
 };
 
 struct HandoffC {
@@ -1430,7 +1592,7 @@ __device__ __forceinline__ uint32_t lane_from_below(uint32_t v)
 
 __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ maskD, const uint32_t* __restrict__ uOld,
                            const uint32_t* __restrict__ uHist, uint32_t* __restrict__ uNew, float* ring, HandoffC hand, uint32_t b,
-                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, bool skipIdle, int& changed)
+                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, bool skipIdle, int& changed, unsigned int* error)
 {
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -1526,8 +1688,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     const bool outGlobal = hasBelow && (b % kCreepWaves) == kCreepWaves - 1;
     const bool inGlobal = b > 0 && (b % kCreepWaves) == 0;
     auto wait_above = [&](uint32_t k) {
-        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
-        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
+        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), error);
     };
     auto load_wblock_above = [&](uint32_t k) -> float {
         const uint32_t xs = min(64 * k + lane, nx - 1) + (kWave - 1);
@@ -1535,8 +1696,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         return ((d >> (xs & 31)) & 1u) ? swf : (float)((u >> (xs & 31)) & 1u);
     };
     auto take_above = [&](uint32_t k, float& fv, float& wv) {
-        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
-        while (lds_observe(&hand.produced[slotIn]) < need) __builtin_amdgcn_s_sleep(1);
+        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), error);
         fv = handIn[(64 * k + lane) % kHandWC];
         const unsigned int code = handInW[(64 * k + lane) % kHandWC];
         wv = (code == 2u) ? swf : (float)code;
@@ -1618,10 +1778,11 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                     lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
                 if (hasBelow) {
                     const unsigned int limit = xpc + kCreepCh - L;
-                    while (true) {
+                    for (unsigned int it = 0;; ++it) {
                         const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
                         if (limit <= (cns & 0x7FFFFu) + kHandWC) break;
                         __builtin_amdgcn_s_sleep(1);
+                        if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(error))) { fail_launch(error, 3); break; }
                     }
                 }
             }
@@ -1795,7 +1956,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
         uint32_t* uNew = maskU + (size_t)(l % a.gens) * maskWords;
         int mine = 0;
         for (uint32_t b = wave; b < nBands; b += kCreepWaves)
-            creep_band(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine);
+            creep_band(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine, a.error);
         changedInLoop = __syncthreads_or(mine);
     }
     // borders (:1464-1489): undefined border cells have r = 0 < repeat in every round, defined ones never change
@@ -1888,16 +2049,62 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         // small batches and short calls: 16 waves x 16 columns; from FILL_WIDE_NZ slices on: 8 waves x 32 columns
         const int geometry = tuning("FILL_GEOMETRY", 0);  // 0: by batch size, 1: 16 x 16, 2: 8 x 32
         const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 8));
-        auto launch = [&](auto kernel, int ch, int waves) {
-            const size_t ldsBytes = (size_t)waves * (kWave + 1) * (2 * ch + 1) * sizeof(float) + (size_t)waves * 2 * kHandW * sizeof(float) +
-                                    (size_t)waves * 4 * sizeof(unsigned int);
-            allow_dynamic_lds(reinterpret_cast<const void*>(kernel), ldsBytes);
-            kernel<<<dim3((uint32_t)nz), waves * kWave, ldsBytes, stream>>>(a);
-        };
-        if (wide) launch(&fill2d_kernel_v2<32, 8>, 32, 8);
-        else launch(&fill2d_kernel_v2<16, 16>, 16, 16);
+        const int waves = wide ? 8 : 16, ch = wide ? 32 : 16;
+        const size_t ldsBytes = (size_t)waves * (kWave + 1) * (2 * ch + 1) * sizeof(float) + (size_t)waves * 2 * kHandW * sizeof(float) +
+                                (size_t)waves * 4 * sizeof(unsigned int);
+        DeviceArray<unsigned int> error(1);
+        FA_HIP(hipMemsetAsync(error.get(), 0, sizeof(unsigned int), stream));
+        a.error = error.get();
+        // Small batches leave most of the chip idle at one workgroup per slice: deal the bands of a slice to several
+        // workgroups (one per CU: the rings fill the LDS), as many as there are groups of `waves` bands and as fit the XCD
+        // the slice's workgroups share with the slices of the same i % 8.
+        // (four waves per workgroup there, one per SIMD: a band's time is the time of its dependent instruction chain, and a
+        // wave that shares its SIMD with three others runs that chain at a quarter of the speed; the critical path of a
+        // sweep -- every band starts ~130 columns behind the one above -- is what a small batch waits for)
+        int mwaves = tuning("FILL_MULTI_WAVES", 4), mch = tuning("FILL_MULTI_CH", 16) == 32 ? 32 : 16;
+        if (!(mwaves == 4 || mwaves == 8 || mwaves == 16)) mwaves = 4;
+        if (mwaves == 16) mch = 16;  // 16 rings of 32 columns do not fit the LDS
+        const size_t bandGroups = ceil_div(nBands, (size_t)mwaves);
+        const size_t perXcd = ceil_div(nz, (size_t)kXcds);  // slices whose workgroups meet on one XCD
+        int cus = 0, dev = 0;
+        FA_HIP(hipGetDevice(&dev));
+        FA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const size_t cusPerXcd = std::max(1, cus / kXcds);
+        size_t groups = std::min(bandGroups, perXcd ? cusPerXcd / perXcd : (size_t)1);
+        if (tuning("FILL_MULTI", 1) == 0 || groups < 2) groups = 1;
+        DeviceArray<unsigned int> sync;
+        if (groups > 1) {
+            a.syncStride = (uint32_t)(4 + nBands);
+            a.groups = (uint32_t)groups;
+            a.nz = (uint32_t)nz;
+            sync.allocate(nz * a.syncStride);
+            FA_HIP(hipMemsetAsync(sync.get(), 0, sync.bytes(), stream));
+            a.sync = sync.get();
+            // more LDS than half a CU has, so that no two of these workgroups share a CU (and its SIMDs)
+            const size_t mlds = std::max<size_t>((size_t)mwaves * (kWave + 1) * (2 * mch + 1) * sizeof(float) + (size_t)mwaves * 2 * kHandW * sizeof(float) +
+                                                     (size_t)mwaves * 4 * sizeof(unsigned int), 84 * 1024);
+            const void* kernel = mwaves == 16  ? reinterpret_cast<const void*>(&fill2d_kernel_v3<16, 16>)
+                                 : mwaves == 8 ? (mch == 32 ? reinterpret_cast<const void*>(&fill2d_kernel_v3<32, 8>) : reinterpret_cast<const void*>(&fill2d_kernel_v3<16, 8>))
+                                               : (mch == 32 ? reinterpret_cast<const void*>(&fill2d_kernel_v3<32, 4>) : reinterpret_cast<const void*>(&fill2d_kernel_v3<16, 4>));
+            allow_dynamic_lds(kernel, mlds);
+            void* params[] = {&a};
+            const dim3 grid((uint32_t)(kXcds * groups * perXcd));
+            // cooperative: every workgroup of the grid is resident (they wait for each other), or the launch fails
+            FA_HIP(hipLaunchCooperativeKernel(kernel, grid, dim3(mwaves * kWave), params, (unsigned int)mlds, stream));
+        } else {
+            auto launch = [&](auto kernel) {
+                allow_dynamic_lds(reinterpret_cast<const void*>(kernel), ldsBytes);
+                kernel<<<dim3((uint32_t)nz), waves * kWave, ldsBytes, stream>>>(a);
+            };
+            if (wide) launch(&fill2d_kernel_v2<32, 8>);
+            else launch(&fill2d_kernel_v2<16, 16>);
+        }
         FA_HIP(hipGetLastError());
-        collect_stats(stats, nz, h_nChanged, stream, "fill2d");
+        unsigned int failed = 0;
+        FA_HIP(hipMemcpyAsync(&failed, error.get(), sizeof(failed), hipMemcpyDeviceToHost, stream));
+        collect_stats(stats, nz, h_nChanged, stream, "fill2d");  // synchronises the stream
+        FA_REQUIRE(failed == 0, "fill2d: a hand-off between waves or workgroups did not arrive (wait " + std::to_string(failed) +
+                                    " gave up); the field is not valid");
         return;
     }
     DeviceArray<float> w(nx * ny * nz);
@@ -1951,10 +2158,17 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         constexpr size_t ldsBytes = (size_t)kCreepWaves * kWave * kCreepPitch * sizeof(float) + (size_t)kCreepWaves * 2 * kHandWC * (sizeof(float) + 1) +
                                     (size_t)kCreepWaves * 4 * sizeof(unsigned int);
         launch_fill_prologue(true, d_field, stats.get(), nx, ny, nz, maskD.get(), mws, nullptr, nullptr, false, useDefault, defaultVal, 0.f, stream);
+        DeviceArray<unsigned int> error(1);
+        FA_HIP(hipMemsetAsync(error.get(), 0, sizeof(unsigned int), stream));
+        a.error = error.get();
         allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
         creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);
         FA_HIP(hipGetLastError());
-        collect_stats(stats, nz, h_nChanged, stream, what);
+        unsigned int failed = 0;
+        FA_HIP(hipMemcpyAsync(&failed, error.get(), sizeof(failed), hipMemcpyDeviceToHost, stream));
+        collect_stats(stats, nz, h_nChanged, stream, what);  // synchronises the stream
+        FA_REQUIRE(failed == 0, std::string(what) + ": a hand-off between waves did not arrive (wait " + std::to_string(failed) +
+                                    " gave up); the field is not valid");
         return;
     }
     DeviceArray<signed char> w(nx * ny * nz);

@@ -11,6 +11,11 @@ def run(cmd):
     print("run:", " ".join(cmd[:8]), "...", flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", timeout=280)
     if r.returncode != 0:
+        # rocprofv3 has been seen to crash in its exit handlers after a run that launched a cooperative kernel (the fills on
+        # small batches): the program's result line and the profiler's files are complete by then
+        if '"case"' in r.stdout:
+            print("note: profiled run ended with status %d after its result line; files kept" % r.returncode, flush=True)
+            return r
         print(r.stdout[-2000:], r.stderr[-2000:], flush=True)
         sys.exit(1)
     return r
@@ -26,7 +31,7 @@ def main():
         work = "/tmp/prof_%s_%s" % (tag, case)
         shutil.rmtree(work, ignore_errors=True)
         r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", work + "/trace", "--"] + prog + [case])
-        runrec = json.loads(r.stdout.strip().splitlines()[-1])
+        runrec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"case"')][-1])
         json.dump(runrec, open(os.path.join(out, "%s_%s_run.json" % (tag, case)), "w"), indent=1)
         ks = glob.glob(work + "/trace/**/*_kernel_stats.csv", recursive=True)[0]
         shutil.copy(ks, os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, case)))

@@ -850,3 +850,26 @@ def test_staged_plan_with_a_seam_and_isolated_points(fa, method, wrap, outliers)
     want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
     assert np.isfinite(want).mean() > 0.8
+
+
+@pytest.mark.parametrize("shape", [(257, 1300, 3), (500, 700, 9), (64, 2100, 2)])
+@pytest.mark.parametrize("params", [(4.0, 1.6, 60), (1e-9, 1.9, 25)])
+@pytest.mark.parametrize("geometry", ["1", "2"], ids=["16waves_x_16columns", "8waves_x_32columns"])
+def test_fill2d_with_several_workgroups_per_slice(fa, monkeypatch, shape, params, geometry, tuning_build):
+    """Small batches of tall slices: the bands of a slice are dealt to several workgroups (fill2d_kernel_v3: hand-off of
+    every W-th band boundary through write-through stores and a global progress word, a barrier of the slice's workgroups
+    per sweep, the convergence test reduced across them).  Same bits as the oracle and as one workgroup per slice."""
+    nx, ny, nz = shape
+    relaxCrit, corrEff, maxLoop = params
+    monkeypatch.setenv("FIMEX_AMD_FILL_GEOMETRY", geometry)
+    f = cases.holes(nz, ny, nx, seed=nx * 7 + ny)
+    monkeypatch.setenv("FIMEX_AMD_FILL_MULTI", "1")
+    got, nch = fa.fill2d_host(f, relaxCrit, corrEff, maxLoop)
+    monkeypatch.setenv("FIMEX_AMD_FILL_MULTI", "0")
+    one, nch1 = fa.fill2d_host(f, relaxCrit, corrEff, maxLoop)
+    assert list(nch) == list(nch1)
+    for z in range(nz):
+        want, wn, rc = oracle.fill2d(f[z], relaxCrit, corrEff, maxLoop)
+        assert rc == oracle.OK and nch[z] == wn
+        assert cases.same(one[z], want), "one workgroup, slice %d: %s" % (z, cases.describe_mismatch(one[z], want))
+        assert cases.same(got[z], want), "several workgroups, slice %d: %s" % (z, cases.describe_mismatch(got[z], want))

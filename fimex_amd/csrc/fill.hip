@@ -1575,6 +1575,10 @@ struct CreepV2Args {
     int sumAlgo;
     int skipIdle;
     unsigned int* error;  // one word per launch: set by a wait that gave up (see MultiWg)
+    // several workgroups per slice (creepfill_kernel_v3): per slice [0] barrier counter, [1..3] "something changed" by sweep
+    // mod 3, [4 .. 4 + bands) progress words of the hand-offs that cross workgroups
+    unsigned int* sync;
+    uint32_t syncStride, groups, nz;
 };
 
 struct HandoffC {
@@ -1590,10 +1594,12 @@ __device__ __forceinline__ uint32_t lane_from_below(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
 }
 
+template <bool MULTI>
 __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ maskD, const uint32_t* __restrict__ uOld,
                            const uint32_t* __restrict__ uHist, uint32_t* __restrict__ uNew, float* ring, HandoffC hand, uint32_t b,
-                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, bool skipIdle, int& changed, unsigned int* error)
+                           uint32_t nx, uint32_t ny, uint32_t mws, float swf, bool skipIdle, int& changed, MultiWg mg)
 {
+    unsigned int* const error = mg.error;
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t y0 = 1 + kWave * b;
@@ -1611,6 +1617,10 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     const uint32_t* hrow = uHist ? uHist + (size_t)y * mws : nullptr;
     uint32_t* nrowU = uNew + (size_t)y * mws;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f + (size_t)(y0 - 1) * nx, 0, (nrow + 2) * nx * 4u, 0x00020000);
+    const bool hasBelow = y0 + nrow < ny - 1;
+    const bool outGlobal = hasBelow && (b % kCreepWaves) == kCreepWaves - 1;
+    const bool inGlobal = b > 0 && (b % kCreepWaves) == 0;
+    const bool writeThrough = MULTI && outGlobal;  // several workgroups per slice: the band below runs on another CU (fill2d_band)
     const uint32_t kOob = 0xFFFFFFFFu;
     // weight of border column 0 of my row: skewed column = lane
     const float wLeft0 = ((drow[lane >> 5] >> (lane & 31)) & 1u) ? swf : 0.f;
@@ -1653,17 +1663,28 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         if (interior(c)) {
             const uint32_t s0 = c * kCreepCh * 4u;
 #pragma unroll
-            for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
+            for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it) {
+                if (writeThrough) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 17);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, voffLane, s0 + it * rowStep, 0);
+            }
             return;
         }
 #pragma unroll
-        for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
+        for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it) {
+            if (writeThrough) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 17);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[it]), rs, chunk_off(c, it, true), 0, 0);
+        }
+    };
+    // this sweep's U word of my row: the band below reads the last row's words (weights of its "up" cells)
+    auto store_u = [&](uint32_t word, uint32_t value) {
+        if (writeThrough) __hip_atomic_store(&nrowU[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else nrowU[word] = value;
     };
     auto load_block = [&](uint32_t rowInBuf, uint32_t k) {
         const uint32_t col = 64 * k + lane;
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col <= nx - 1 ? (rowInBuf * nx + col) * 4u : kOob, 0, 0));
+        const uint32_t off = col <= nx - 1 ? (rowInBuf * nx + col) * 4u : kOob;
+        if (MULTI && inGlobal && rowInBuf == 0) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 17));  // see fill2d_band
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
     };
     // weights of 64 columns of an unskewed row (row 0, the first row of the band below, row ny - 1)
     auto load_wblock = [&](uint32_t yRow, uint32_t k) -> float {
@@ -1672,8 +1693,9 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         return ((d >> (col & 31)) & 1u) ? swf : (float)((u >> (col & 31)) & 1u);
     };
 
-    const uint32_t slotOut = (b % kCreepWaves) * 2 + ((b / kCreepWaves) & 1);
-    const uint32_t slotIn = ((b - 1) % kCreepWaves) * 2 + (((b - 1) / kCreepWaves) & 1);
+    const uint32_t round = kCreepWaves * (MULTI ? mg.G : 1u);
+    const uint32_t slotOut = (b % kCreepWaves) * 2 + ((b / round) & 1);
+    const uint32_t slotIn = ((b - 1) % kCreepWaves) * 2 + (((b - 1) / round) & 1);
     float* handOut = hand.data + slotOut * kHandWC;
     unsigned char* handOutW = hand.wcode + slotOut * kHandWC;
     const float* handIn = hand.data + slotIn * kHandWC;
@@ -1684,15 +1706,15 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     }
     // every 16th boundary goes through global memory (see fill2d_band): values from the flushed row, weights from the
     // D mask and this sweep's U words of that row (skew 63), which the producing band stores at every event
-    const bool hasBelow = y0 + nrow < ny - 1;
-    const bool outGlobal = hasBelow && (b % kCreepWaves) == kCreepWaves - 1;
-    const bool inGlobal = b > 0 && (b % kCreepWaves) == 0;
     auto wait_above = [&](uint32_t k) {
+        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], min(64 * k + 64, C + 1) + 1, error); return; }
         wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), error);
     };
     auto load_wblock_above = [&](uint32_t k) -> float {
         const uint32_t xs = min(64 * k + lane, nx - 1) + (kWave - 1);
-        const uint32_t d = maskD[(size_t)(y0 - 1) * mws + (xs >> 5)], u = uNew[(size_t)(y0 - 1) * mws + (xs >> 5)];
+        const uint32_t d = maskD[(size_t)(y0 - 1) * mws + (xs >> 5)];
+        const uint32_t u = MULTI ? __hip_atomic_load(&uNew[(size_t)(y0 - 1) * mws + (xs >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : uNew[(size_t)(y0 - 1) * mws + (xs >> 5)];
         return ((d >> (xs & 31)) & 1u) ? swf : (float)((u >> (xs & 31)) & 1u);
     };
     auto take_above = [&](uint32_t k, float& fv, float& wv) {
@@ -1740,14 +1762,16 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             if (outGlobal) {
                 if (xpc > L) {  // stores of the previous event have landed: columns < 16 (c - 1) - L of the last row, values and U bits
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0 && xpc - kCreepCh > L)
-                        lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCreepCh - L));
+                    if (lane == 0 && xpc - kCreepCh > L) {
+                        if (MULTI) __hip_atomic_store(&mg.flags[b], xpc - kCreepCh - L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCreepCh - L));
+                    }
                 }
-                if (rowValid) nrowU[(c - 1) / kCreepChunksPerWord] = un;  // the (partial) word of the chunk just finished
+                if (rowValid) store_u((c - 1) / kCreepChunksPerWord, un);  // the (partial) word of the chunk just finished
             }
             // small loads first, the chunk prefetch last (see fill2d_band)
             if ((c % kCreepChunksPerWord) == 0) {  // x' is a multiple of 32: the finished U word goes out, every lane switches words
-                if (rowValid) nrowU[c / kCreepChunksPerWord - 1] = un;
+                if (rowValid) store_u(c / kCreepChunksPerWord - 1, un);
                 un = 0;
                 const uint32_t nxt = min(c / kCreepChunksPerWord + 2, wLast);
                 dw = dwN; dwN = dwLd; dwLd = drow[nxt];
@@ -1913,9 +1937,12 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
         }
     }
     flush_chunk(nChunks - 1);
-    if (rowValid) nrowU[(nChunks - 1) / kCreepChunksPerWord] = un;
+    if (rowValid) store_u((nChunks - 1) / kCreepChunksPerWord, un);
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
+    if (lane == 0) {
+        if (MULTI && outGlobal) __hip_atomic_store(&mg.flags[b], C + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_publish(&hand.produced[slotOut], hand_tag(b, C + 1));
+    }
 }
 
 __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args a)
@@ -1956,7 +1983,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
         uint32_t* uNew = maskU + (size_t)(l % a.gens) * maskWords;
         int mine = 0;
         for (uint32_t b = wave; b < nBands; b += kCreepWaves)
-            creep_band(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine, a.error);
+            creep_band<false>(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine, MultiWg{0u, 1u, nullptr, a.error});
         changedInLoop = __syncthreads_or(mine);
     }
     // borders (:1464-1489): undefined border cells have r = 0 < repeat in every round, defined ones never change
@@ -1988,6 +2015,107 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
         for (uint32_t x = threadIdx.x; x < nx; x += kCreepThreads) {
             const size_t bo = (size_t)nym1 * nx + x;
             const bool edge = (x == 0 || x == nxm1);  // the neighbour is a border cell of the column loop above: w = 1 if it was undefined
+            if (!defined(0, x)) {
+                const int wn = edge ? (defined(1, x) ? a.setWeight : 1) : w_interior(1, x);
+                f[x] += f[nx + x] * wn;
+                f[x] /= (float)(1 + wn);
+            }
+            if (!defined(nym1, x)) {
+                const int wn = edge ? (defined(nym1 - 1, x) ? a.setWeight : 1) : w_interior(nym1 - 1, x);
+                f[bo] += f[bo - nx] * wn;
+                f[bo] /= (float)(1 + wn);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The sweeps of creepfill_kernel_v2 with the bands of a slice dealt to a.groups workgroups (MultiWg, fill2d_kernel_v3); the
+// border rounds that follow the sweeps are little work and stay with the slice's first workgroup.
+__global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v3(CreepV2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rings = smem;
+    HandoffC hand;
+    hand.data = smem + kCreepWaves * kWave * kCreepPitch;
+    hand.wcode = reinterpret_cast<unsigned char*>(hand.data + kCreepWaves * 2 * kHandWC);
+    hand.produced = reinterpret_cast<unsigned int*>(hand.wcode + kCreepWaves * 2 * kHandWC);
+    hand.consumed = hand.produced + kCreepWaves * 2;
+    const uint32_t G = a.groups;
+    const uint32_t slice = (blockIdx.x % kXcds) + kXcds * (blockIdx.x / (kXcds * G));
+    const uint32_t g = (blockIdx.x / kXcds) % G;
+    if (slice >= a.nz) return;
+    const uint32_t nx = a.nx, ny = a.ny, mws = a.mws;
+    const size_t total = (size_t)nx * ny;
+    const size_t maskWords = (size_t)ny * mws;
+    float* f = a.field + (size_t)slice * total;
+    uint32_t* maskD = a.maskD + (size_t)slice * maskWords;
+    uint32_t* maskU = a.maskU + (size_t)slice * a.gens * maskWords;
+    SliceStats* st = a.stats + slice;
+    unsigned int* sync = a.sync + (size_t)slice * a.syncStride;
+    const MultiWg mg{g, G, sync + 4, a.error};
+    const uint32_t wave = threadIdx.x / kWave;
+    if (st->skip) return;  // :1384-1386, :1515
+    const unsigned long long nDef = total - st->nUndef;
+    const uint32_t repeat = a.repeat;
+    const float swf = (float)a.setWeight;
+    const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
+    const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
+    float* ring = rings + wave * kWave * kCreepPitch;
+    unsigned long long l = 0;
+    unsigned int barriers = 0;
+    int changedInLoop = 1;
+    while (repeat > 0 && changedInLoop && l < nDef) {  // :1430
+        l++;
+        if (threadIdx.x < kCreepWaves * 2) { hand.produced[threadIdx.x] = 0; hand.consumed[threadIdx.x] = 0; }
+        __syncthreads();
+        const uint32_t* uOld = maskU + (size_t)((l - 1) % a.gens) * maskWords;
+        const uint32_t* uHist = (l > repeat) ? maskU + (size_t)((l - repeat) % a.gens) * maskWords : nullptr;
+        uint32_t* uNew = maskU + (size_t)(l % a.gens) * maskWords;
+        int mine = 0;
+        for (uint32_t b = g * kCreepWaves + wave; b < nBands; b += G * kCreepWaves)
+            creep_band<true>(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine, mg);
+        unsigned int* changedWord = sync + 1 + (unsigned int)(l % 3);
+        if (__syncthreads_or(mine) && threadIdx.x == 0) __hip_atomic_fetch_or(changedWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slice_barrier(sync, ++barriers * G, a.error);
+        if (launch_failed(a.error)) return;
+        changedInLoop = __hip_atomic_load(changedWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        // the word of the sweep after next (nobody adds to it before the next barrier, which this workgroup has yet to reach),
+        // and this workgroup's progress words for the next sweep
+        if (g == 0 && threadIdx.x == 0) __hip_atomic_store(sync + 1 + (unsigned int)((l + 2) % 3), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t b = g * kCreepWaves + kCreepWaves - 1 + threadIdx.x * G * kCreepWaves; b < nBands; b += kCreepThreads * G * kCreepWaves)
+            __hip_atomic_store(mg.flags + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (g != 0) return;
+    // borders (:1464-1489), as in creepfill_kernel_v2: everything the other workgroups wrote is visible behind the last barrier
+    const uint32_t* uFin = maskU + (size_t)(l % a.gens) * maskWords;
+    auto defined = [&](uint32_t y, uint32_t x) -> bool {
+        const uint32_t sk = (y == 0 || y == nym1) ? 0u : ((y - 1) & (kWave - 1));
+        return (maskD[(size_t)y * mws + ((x + sk) >> 5)] >> ((x + sk) & 31)) & 1u;
+    };
+    auto w_interior = [&](uint32_t y, uint32_t x) -> int {
+        const uint32_t sk = (y - 1) & (kWave - 1);
+        if (defined(y, x)) return a.setWeight;
+        return (uFin[(size_t)y * mws + ((x + sk) >> 5)] >> ((x + sk) & 31)) & 1u;
+    };
+    for (uint32_t k = 0; k < repeat; ++k) {
+        for (uint32_t y = 1 + threadIdx.x; y < nym1; y += kCreepThreads) {
+            const size_t row = (size_t)y * nx;
+            if (!defined(y, 0)) {
+                const int wn = w_interior(y, 1);
+                f[row] += f[row + 1] * wn;
+                f[row] /= (float)(1 + wn);
+            }
+            if (!defined(y, nxm1)) {
+                const int wn = w_interior(y, nx - 2);
+                f[row + nxm1] += f[row + nx - 2] * wn;
+                f[row + nxm1] /= (float)(1 + wn);
+            }
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < nx; x += kCreepThreads) {
+            const size_t bo = (size_t)nym1 * nx + x;
+            const bool edge = (x == 0 || x == nxm1);
             if (!defined(0, x)) {
                 const int wn = edge ? (defined(1, x) ? a.setWeight : 1) : w_interior(1, x);
                 f[x] += f[nx + x] * wn;
@@ -2161,8 +2289,30 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         DeviceArray<unsigned int> error(1);
         FA_HIP(hipMemsetAsync(error.get(), 0, sizeof(unsigned int), stream));
         a.error = error.get();
-        allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
-        creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);
+        // small batches: the bands of a slice on several workgroups (see run_fill2d)
+        const size_t bandGroups = ceil_div(nBands, (size_t)kCreepWaves);
+        const size_t perXcd = ceil_div(nz, (size_t)kXcds);
+        int cus = 0, dev = 0;
+        FA_HIP(hipGetDevice(&dev));
+        FA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        size_t groups = std::min(bandGroups, perXcd ? (size_t)std::max(1, cus / kXcds) / perXcd : (size_t)1);
+        if (tuning("FILL_MULTI", 1) == 0 || groups < 2) groups = 1;
+        DeviceArray<unsigned int> sync;
+        if (groups > 1) {
+            a.syncStride = (uint32_t)(4 + nBands);
+            a.groups = (uint32_t)groups;
+            a.nz = (uint32_t)nz;
+            sync.allocate(nz * a.syncStride);
+            FA_HIP(hipMemsetAsync(sync.get(), 0, sync.bytes(), stream));
+            a.sync = sync.get();
+            const void* kernel = reinterpret_cast<const void*>(&creepfill_kernel_v3);
+            allow_dynamic_lds(kernel, ldsBytes);
+            void* params[] = {&a};
+            FA_HIP(hipLaunchCooperativeKernel(kernel, dim3((uint32_t)(kXcds * groups * perXcd)), dim3(kCreepThreads), params, (unsigned int)ldsBytes, stream));
+        } else {
+            allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
+            creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);
+        }
         FA_HIP(hipGetLastError());
         unsigned int failed = 0;
         FA_HIP(hipMemcpyAsync(&failed, error.get(), sizeof(failed), hipMemcpyDeviceToHost, stream));

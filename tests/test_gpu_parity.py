@@ -873,3 +873,27 @@ def test_fill2d_with_several_workgroups_per_slice(fa, monkeypatch, shape, params
         assert rc == oracle.OK and nch[z] == wn
         assert cases.same(one[z], want), "one workgroup, slice %d: %s" % (z, cases.describe_mismatch(one[z], want))
         assert cases.same(got[z], want), "several workgroups, slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+
+
+@pytest.mark.parametrize("shape", [(257, 1300, 3), (500, 700, 9), (64, 2100, 1)])
+@pytest.mark.parametrize("params", [(20, 2), (3, 1), (40, 5)])
+def test_creepfill_with_several_workgroups_per_slice(fa, monkeypatch, shape, params, tuning_build):
+    """creepfill_kernel_v3: the bands of a slice on several workgroups (values and this sweep's U words of a band's last row
+    cross workgroups write-through, "something changed" is reduced over the slice's workgroups every sweep).  Same bits as
+    the oracle and as one workgroup per slice, for creepfill2d and creepfillval2d."""
+    nx, ny, nz = shape
+    repeat, weight = params
+    f = cases.holes(nz, ny, nx, seed=nx * 5 + ny + repeat)
+    monkeypatch.setenv("FIMEX_AMD_FILL_MULTI", "1")
+    got, nch = fa.creepfill2d_host(f, repeat, weight)
+    gotv, nchv = fa.creepfillval2d_host(f, 271.5, repeat, weight)
+    monkeypatch.setenv("FIMEX_AMD_FILL_MULTI", "0")
+    one, nch1 = fa.creepfill2d_host(f, repeat, weight)
+    assert list(nch) == list(nch1)
+    for z in range(nz):
+        want, wn = oracle.creepfill2d(f[z], repeat, weight)[:2]
+        assert nch[z] == wn
+        assert cases.same(one[z], want), "one workgroup, slice %d: %s" % (z, cases.describe_mismatch(one[z], want))
+        assert cases.same(got[z], want), "several workgroups, slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+        wantv = oracle.creepfillval2d(f[z], 271.5, repeat, weight)[0]
+        assert cases.same(gotv[z], wantv), "creepfillval2d, slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))

@@ -56,6 +56,7 @@ SYMBOLS = {
     "fimex_amd_abi_version": (ctypes.c_int, []),
     "fimex_amd_device_count": (ctypes.c_int, []),
     "fimex_amd_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "fimex_amd_release_caches": (ctypes.c_int, []),
     "fimex_amd_regrid_plan_create": (ctypes.c_int, [ctypes.c_int, _D, _D, _Z, _Z, _Z, _Z, _Z, ctypes.POINTER(_V)]),
     "fimex_amd_regrid_plan_create_device": (ctypes.c_int, [ctypes.c_int, _V, _V, _Z, _Z, _Z, _Z, _Z, _V, ctypes.POINTER(_V)]),
     "fimex_amd_regrid_plan_create_opt": (ctypes.c_int, [ctypes.c_int, _D, _D, _Z, _Z, _Z, _Z, _Z, ctypes.c_int, ctypes.POINTER(_V)]),
@@ -159,6 +160,10 @@ def use_tuning_build(on=True):
 def _check(rc):
     if rc != OK:
         raise FimexAmdError(load().fimex_amd_last_error().decode() or "fimex_amd call failed")
+
+
+def release_caches():
+    _check(load().fimex_amd_release_caches())
 
 
 def device_count():

@@ -149,6 +149,11 @@ extern "C" {
 
 const char* fimex_amd_last_error(void) { return g_lastError.c_str(); }
 
+int fimex_amd_release_caches(void)
+{
+    return c_guard([&] { release_host_pipes(); });
+}
+
 int fimex_amd_abi_version(void) { return 120; }  // 1.20: plan constructors with the bicubic arithmetic, release of cached buffers
 
 int fimex_amd_device_count(void) { return usable_device_count(); }

@@ -21,7 +21,8 @@ constexpr size_t kDevFloatBytes = (size_t)128 << 20;  // float scratch per slot 
 constexpr int kSlots = 3;
 constexpr size_t kPiece = (size_t)8 << 20;            // a slot's transfer goes in pieces: host memcpy of one overlaps the DMA of the other
 constexpr int kPieces = (int)(kPinBytes / kPiece);
-constexpr int kMaxCached = 4;
+constexpr int kMaxCached = 4;  // idle pipes kept for the next call
+constexpr int kMaxLive = 8;    // pipes in use at once: further callers wait for one (each pins up to 384 MB of host memory)
 
 // memcpy on several threads: the workers live as long as the pipe
 class ParallelCopier {
@@ -96,17 +97,13 @@ struct Slot {
     hipEvent_t piece[kPieces] = {};   // piece p of the result has arrived in pinOut
 };
 
+// Buffers are made on first use and only the kind a call needs: host_to_device touches pinIn alone, a float regrid the four
+// raw buffers, only a conversion of stored types the float scratch (3 x 256 MB of HBM otherwise held for nothing).
 class HostPipe {
 public:
     explicit HostPipe(int device) : device(device), copier(worker_count())
     {
         for (Slot& s : slots) {
-            FA_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pinIn), kPinBytes));
-            FA_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pinOut), kPinBytes));
-            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dRawIn), kPinBytes));
-            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dRawOut), kPinBytes));
-            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFIn), kDevFloatBytes));
-            FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFOut), kDevFloatBytes));
             FA_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             FA_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
             for (hipEvent_t& e : s.piece) FA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -127,6 +124,16 @@ public:
             if (s.stream) (void)hipStreamDestroy(s.stream);
         }
     }
+    enum Need { PinIn = 1, PinOut = 2, RawIn = 4, RawOut = 8, FloatIn = 16, FloatOut = 32 };
+    void ensure(Slot& s, int need)
+    {
+        if ((need & PinIn) && !s.pinIn) FA_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pinIn), kPinBytes));
+        if ((need & PinOut) && !s.pinOut) FA_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.pinOut), kPinBytes));
+        if ((need & RawIn) && !s.dRawIn) FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dRawIn), kPinBytes));
+        if ((need & RawOut) && !s.dRawOut) FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dRawOut), kPinBytes));
+        if ((need & FloatIn) && !s.dFIn) FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFIn), kDevFloatBytes));
+        if ((need & FloatOut) && !s.dFOut) FA_HIP(hipMalloc(reinterpret_cast<void**>(&s.dFOut), kDevFloatBytes));
+    }
     static int worker_count()
     {
         const int forced = tuning("HOST_COPY_THREADS", 0);
@@ -140,12 +147,17 @@ public:
 };
 
 std::mutex g_poolMutex;
+std::condition_variable g_poolFree;
 std::vector<HostPipe*> g_pool;
+int g_live = 0;  // pipes handed out
 
 HostPipe* acquire_pipe(int device)
 {
     {
-        std::lock_guard<std::mutex> l(g_poolMutex);
+        std::unique_lock<std::mutex> l(g_poolMutex);
+        // concurrent callers (interpolateValues is re-entrant) get a pipe each, up to kMaxLive; the next one waits
+        g_poolFree.wait(l, [] { return g_live < kMaxLive; });
+        ++g_live;
         for (size_t i = 0; i < g_pool.size(); ++i)
             if (g_pool[i]->device == device) {
                 HostPipe* p = g_pool[i];
@@ -153,16 +165,25 @@ HostPipe* acquire_pipe(int device)
                 return p;
             }
     }
-    return new HostPipe(device);  // concurrent callers (interpolateValues is re-entrant) each get their own
+    try {
+        return new HostPipe(device);
+    } catch (...) {
+        { std::lock_guard<std::mutex> l(g_poolMutex); --g_live; }
+        g_poolFree.notify_one();
+        throw;
+    }
 }
 
 void release_pipe(HostPipe* p)
 {
+    bool keep = false;
     {
         std::lock_guard<std::mutex> l(g_poolMutex);
-        if ((int)g_pool.size() < kMaxCached) { g_pool.push_back(p); return; }
+        --g_live;
+        if ((int)g_pool.size() < kMaxCached) { g_pool.push_back(p); keep = true; }
     }
-    delete p;
+    g_poolFree.notify_one();
+    if (!keep) delete p;
 }
 
 struct PipeLease {
@@ -186,7 +207,10 @@ bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out
     nzc = std::min(nzc, nz);
     PipeLease lease(device);
     HostPipe& p = *lease.pipe;
+    const int need = HostPipe::PinIn | HostPipe::PinOut | HostPipe::RawIn | HostPipe::RawOut | (inSliceFloats ? HostPipe::FloatIn : 0) |
+                     (outSliceFloats ? HostPipe::FloatOut : 0);
     const size_t nChunks = (nz + nzc - 1) / nzc;
+    for (size_t c = 0; c < std::min<size_t>(nChunks, kSlots); ++c) p.ensure(p.slots[c], need);
     const char* src = static_cast<const char*>(in);
     char* dst = static_cast<char*>(out);
     auto count = [&](size_t c) { return std::min(nzc, nz - c * nzc); };
@@ -245,6 +269,7 @@ void host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t st
     PipeLease lease(device);
     HostPipe& p = *lease.pipe;
     const size_t nChunks = (bytes + kPinBytes - 1) / kPinBytes;
+    for (size_t c = 0; c < std::min<size_t>(nChunks, kSlots); ++c) p.ensure(p.slots[c], HostPipe::PinIn);
     try {
         for (size_t c = 0; c < nChunks; ++c) {
             Slot& s = p.slots[c % kSlots];
@@ -275,6 +300,7 @@ void device_to_host(void* h_dst, const void* d_src, size_t bytes, hipStream_t st
     PipeLease lease(device);
     HostPipe& p = *lease.pipe;
     const size_t nChunks = (bytes + kPinBytes - 1) / kPinBytes;
+    for (size_t c = 0; c < std::min<size_t>(nChunks, kSlots); ++c) p.ensure(p.slots[c], HostPipe::PinOut);
     auto finish = [&](size_t c) {
         Slot& s = p.slots[c % kSlots];
         FA_HIP(hipEventSynchronize(s.done));
@@ -294,6 +320,24 @@ void device_to_host(void* h_dst, const void* d_src, size_t bytes, hipStream_t st
     } catch (...) {
         for (Slot& s : p.slots) (void)hipStreamSynchronize(s.stream);
         throw;
+    }
+}
+
+// frees the idle pipes (pinned host memory, device staging, copy threads); pipes in use are freed when their call returns and
+// the cache is full, or by the next call of this
+void release_host_pipes()
+{
+    std::vector<HostPipe*> idle;
+    {
+        std::lock_guard<std::mutex> l(g_poolMutex);
+        idle.swap(g_pool);
+    }
+    for (HostPipe* p : idle) {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(p->device);
+        delete p;
+        (void)hipSetDevice(prev);
     }
 }
 

@@ -169,6 +169,7 @@ bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out
 
 void host_to_device(void* d_dst, const void* h_src, size_t bytes, hipStream_t stream);
 void device_to_host(void* h_dst, const void* d_src, size_t bytes, hipStream_t stream);
+void release_host_pipes();
 
 // tuning knobs read once from the environment (FIMEX_AMD_<NAME>), for bench sweeps
 int tuning(const char* name, int fallback);

@@ -62,6 +62,10 @@ extern "C" {
 const char* fimex_amd_last_error(void);
 /** ABI version of this header (major*100 + minor). */
 int fimex_amd_abi_version(void);
+/** The *_host entry points stream caller buffers through pinned staging that is kept between calls (up to 4 idle sets of
+ *  at most 384 MB pinned host memory and 384 MB - 1.1 GB of device memory each, allocated on first use; at most 8 in use at
+ *  once, further concurrent callers wait).  This frees the idle ones. */
+int fimex_amd_release_caches(void);
 /** Number of usable gfx950 devices (0 when there is none; never an error). */
 int fimex_amd_device_count(void);
 /** Device the calling thread creates plans on (hipSetDevice). */

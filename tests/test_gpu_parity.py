@@ -897,3 +897,22 @@ def test_creepfill_with_several_workgroups_per_slice(fa, monkeypatch, shape, par
         assert cases.same(got[z], want), "several workgroups, slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
         wantv = oracle.creepfillval2d(f[z], 271.5, repeat, weight)[0]
         assert cases.same(gotv[z], wantv), "creepfillval2d, slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))
+
+
+def test_release_caches_between_host_calls(fa):
+    """fimex_amd_release_caches frees the pinned staging the *_host calls keep between calls; the next call builds it again
+    (buffers are made on first use and only the kind a call needs)."""
+    inX, inY, outX, outY, nz = 700, 500, 400, 300, 40  # 56 MB in: the streamed path
+    px, py = cases.coherent_positions(inX, inY, outX, outY, seed=41)
+    f = cases.field(nz, inY, inX, seed=42)
+    plan = fa.RegridPlan(fa.BILINEAR, px, py, inX, inY, outX, outY)
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
+    assert cases.same(plan.apply_host(f), want)
+    fa.release_caches()
+    fa.release_caches()
+    assert cases.same(plan.apply_host(f), want)
+    packed = (f * 10).astype(np.int16)
+    got = fa.regrid_slice_typed_host(plan, packed[:8], -32767.0)
+    fa.release_caches()
+    assert cases.same(plan.apply_host(f[:3]), want[:3])
+    assert got.dtype == np.int16

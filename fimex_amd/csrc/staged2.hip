@@ -304,8 +304,25 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first DEPTH - 1 slices (a workgroup's first wait only)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    auto run = [&](auto unTag) {
+    // A wave whose outputs are all interior cells of the source (nothing undefined, no border branch: nearly every wave)
+    // runs a copy of the loop without the selections between the border forms.
+    bool plainWave = true;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        plainWave = plainWave && !undef[k] && (STENCIL != 2 || ((__float_as_uint(xf[k]) | __float_as_uint(yf[k])) >> 31) == 0);
+    plainWave = __all(plainWave) != 0;
+    // selection masks of the border forms (interpolation.c:903-948) for the other copy: all ones / all zeros per output
+    uint32_t mNnx[PER], mNny[PER], mUndef[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        mNnx[k] = (uint32_t)((int32_t)__float_as_uint(xf[k]) >> 31);
+        mNny[k] = (uint32_t)((int32_t)__float_as_uint(yf[k]) >> 31);
+        mUndef[k] = undef[k] ? 0xFFFFFFFFu : 0u;
+    }
+    auto pick = [](uint32_t mask, float a, float b) { return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask)); };
+    auto run = [&](auto unTag, auto plainTag) __attribute__((always_inline)) {
         constexpr int UN = decltype(unTag)::value;
+        constexpr bool PLAIN = decltype(plainTag)::value;
         uint32_t slot = 0;
         for (uint32_t i = 0; i < nzl; ++i) {
             const uint32_t z = z0 + i;
@@ -325,7 +342,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                 for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
     #pragma unroll
                 for (int k = 0; k < PER; ++k)  // src/interpolation.c:869-876
-                    __builtin_amdgcn_raw_buffer_store_b32(undef[k] ? 0x7fc00000u : __float_as_uint(v[k]), ro, cellOff[k], 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(PLAIN ? v[k] : pick(mUndef[k], undefined_f(), v[k])), ro, cellOff[k], 0, 2);
             } else if constexpr (STENCIL == 2) {
                 float s00[PER], s01[PER], s10[PER], s11[PER];
     #pragma unroll
@@ -336,14 +353,16 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                 }
     #pragma unroll
                 for (int k = 0; k < PER; ++k) {
-                    const bool nnx = (__float_as_uint(xf[k]) >> 31) != 0, nny = (__float_as_uint(yf[k]) >> 31) != 0;
                     // interior (interpolation.c:899-900); its upper row is the "linear in x, nearest in y" value (:911)
                     const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];
                     const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];
                     const float inter = (1.f - yf[k]) * top + yf[k] * bot;
-                    const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
-                    float r = nnx ? (nny ? s00[k] : liny) : (nny ? top : inter);
-                    r = undef[k] ? undefined_f() : r;
+                    float r = inter;
+                    if constexpr (!PLAIN) {  // every form is computed, bit masks pick one: no divergent branches in the loop
+                        const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // nearest in x, linear in y (:931)
+                        r = pick(mNnx[k], pick(mNny[k], s00[k], liny), pick(mNny[k], top, inter));
+                        r = pick(mUndef[k], undefined_f(), r);
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
                 }
             } else {
@@ -373,7 +392,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                             acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(undef[k] ? undefined_f() : acc), ro, cellOff[k], 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(PLAIN ? acc : pick(mUndef[k], undefined_f(), acc)), ro, cellOff[k], 0, 2);
                 }
             }
             if (more) wait_vmcnt<(DEPTH - 2) * UN + (DEPTH - 1) * PER>();
@@ -384,15 +403,19 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
         }
     };
     static_assert(KMAX <= 8, "one copy of the loop per DMA count");
+    auto run_un = [&](auto unTag) __attribute__((always_inline)) {
+        if (plainWave) run(unTag, std::true_type());
+        else run(unTag, std::false_type());
+    };
     switch (un) {
-    case 1: run(std::integral_constant<int, 1>()); break;
-    case 2: run(std::integral_constant<int, KMAX >= 2 ? 2 : 1>()); break;
-    case 3: run(std::integral_constant<int, KMAX >= 3 ? 3 : 1>()); break;
-    case 4: run(std::integral_constant<int, KMAX >= 4 ? 4 : 1>()); break;
-    case 5: run(std::integral_constant<int, KMAX >= 5 ? 5 : 1>()); break;
-    case 6: run(std::integral_constant<int, KMAX >= 6 ? 6 : 1>()); break;
-    case 7: run(std::integral_constant<int, KMAX >= 7 ? 7 : 1>()); break;
-    default: run(std::integral_constant<int, KMAX >= 8 ? 8 : 1>()); break;
+    case 1: run_un(std::integral_constant<int, 1>()); break;
+    case 2: run_un(std::integral_constant<int, KMAX >= 2 ? 2 : 1>()); break;
+    case 3: run_un(std::integral_constant<int, KMAX >= 3 ? 3 : 1>()); break;
+    case 4: run_un(std::integral_constant<int, KMAX >= 4 ? 4 : 1>()); break;
+    case 5: run_un(std::integral_constant<int, KMAX >= 5 ? 5 : 1>()); break;
+    case 6: run_un(std::integral_constant<int, KMAX >= 6 ? 6 : 1>()); break;
+    case 7: run_un(std::integral_constant<int, KMAX >= 7 ? 7 : 1>()); break;
+    default: run_un(std::integral_constant<int, KMAX >= 8 ? 8 : 1>()); break;
     }
 }
 

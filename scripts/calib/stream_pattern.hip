@@ -140,6 +140,13 @@ __global__ void __launch_bounds__(PRIV ? 256 : NT) tile(Args a)
             const float bot = (1.f - w0[k]) * s10[k] + w0[k] * s11[k];
             rr[k] = (1.f - w1[k]) * top + w1[k] * bot;
         }
+        if (a.flags & 1536) {  // extra arithmetic per output (512: 32 dependent FMAs, 1024: 96): is the loop's ALU time hidden?
+            const int n = ((a.flags & 512) ? 32 : 0) + ((a.flags & 1024) ? 96 : 0);
+            for (int q = 0; q < n; ++q) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) rr[k] = __builtin_fmaf(rr[k], 1.0000001f, w1[k]);
+            }
+        }
         if (quad && PER == 4) {
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
             const u4 v = {__float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3])};
@@ -623,6 +630,13 @@ int main(int argc, char** argv)
         run_sb<1024, 4, 4, 2, 4>(in, out, nz, 512, 48);
         run_sb<1024, 4, 4, 2, 8>(in, out, nz, 512, 48);
         run_sb<1024, 4, 4, 2, 12>(in, out, nz, 512, 48);
+    }
+
+    if (want("alu")) {
+        for (uint32_t flags : {0u, 512u, 1024u, 1536u, 3u, 512u + 3u, 1024u + 3u, 1536u + 3u}) {
+            run_tile<1024, 4, 4, 2, false>("alu", in, out, nz, 512, 50, flags);
+            run_tile<256, 4, 4, 2, false>("alu", in, out, nz, 128, 50, flags);
+        }
     }
     CK(hipFree(in));
     CK(hipFree(out));

@@ -2217,9 +2217,14 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
             allow_dynamic_lds(kernel, mlds);
             void* params[] = {&a};
             const dim3 grid((uint32_t)(kXcds * groups * perXcd));
-            // cooperative: every workgroup of the grid is resident (they wait for each other), or the launch fails
-            FA_HIP(hipLaunchCooperativeKernel(kernel, grid, dim3(mwaves * kWave), params, (unsigned int)mlds, stream));
-        } else {
+            // cooperative: every workgroup of the grid is resident (they wait for each other), or the launch is refused -- then
+            // one workgroup per slice does the work
+            if (hipLaunchCooperativeKernel(kernel, grid, dim3(mwaves * kWave), params, (unsigned int)mlds, stream) != hipSuccess) {
+                (void)hipGetLastError();
+                groups = 1;
+            }
+        }
+        if (groups <= 1) {
             auto launch = [&](auto kernel) {
                 allow_dynamic_lds(reinterpret_cast<const void*>(kernel), ldsBytes);
                 kernel<<<dim3((uint32_t)nz), waves * kWave, ldsBytes, stream>>>(a);
@@ -2308,8 +2313,13 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
             const void* kernel = reinterpret_cast<const void*>(&creepfill_kernel_v3);
             allow_dynamic_lds(kernel, ldsBytes);
             void* params[] = {&a};
-            FA_HIP(hipLaunchCooperativeKernel(kernel, dim3((uint32_t)(kXcds * groups * perXcd)), dim3(kCreepThreads), params, (unsigned int)ldsBytes, stream));
-        } else {
+            if (hipLaunchCooperativeKernel(kernel, dim3((uint32_t)(kXcds * groups * perXcd)), dim3(kCreepThreads), params, (unsigned int)ldsBytes, stream) !=
+                hipSuccess) {  // refused (not every workgroup would be resident): one workgroup per slice
+                (void)hipGetLastError();
+                groups = 1;
+            }
+        }
+        if (groups <= 1) {
             allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);
             creepfill_kernel_v2<<<dim3((uint32_t)nz), kCreepThreads, ldsBytes, stream>>>(a);
         }

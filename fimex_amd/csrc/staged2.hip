@@ -240,9 +240,15 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
             if (undef[k]) p[k] = 0;
         }
         const uint32_t inRec = (kTuningBuild && (a.flags & 1)) ? 0u : a.inBytes;
+        // (the slice pointers are wave-uniform; said explicitly, or the compiler loops over the lanes' descriptors)
+        auto uniform = [](const char* ptr) {
+            const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        };
         for (uint32_t z = z0; z < z1; ++z) {
-            const rsrc_t rs = make_rsrc(inBase + (size_t)z * a.inBytes, inRec);
-            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+            const rsrc_t rs = make_rsrc(uniform(inBase + (size_t)z * a.inBytes), inRec);
+            const rsrc_t ro = make_rsrc(uniform(outBase + (size_t)z * outBytes), outRecords);
             auto ld = [&](uint32_t cell) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cell * 4u, 0, 0)); };
 #pragma unroll
             for (int k = 0; k < PER; ++k) {

@@ -61,7 +61,47 @@ struct FwdArgs {
 template <bool UNDEF>
 __device__ __forceinline__ bool keep(float v) { return UNDEF || !isnan(v); }
 
-// sum / mean / max / min over one bucket, ZC slices at a time, one lane per target cell
+// One bucket, ZC slices at a time: sum / mean / max / min (KIND 0 / 1 / 3 / 4) and the median of buckets of at most two
+// source cells (KIND 5: rank size()/2 of one value is the value, of two the larger one -- the second where they compare equal,
+// which is what counting "less, or equal and earlier" picks, src/CachedForwardInterpolation.cc:49-53).
+template <int KIND, bool UNDEF, int ZC>
+__device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint32_t e, const float* src, const size_t (&koff)[ZC], float (&r)[ZC])
+{
+    float acc[ZC], second[ZC];
+    uint32_t cnt[ZC];
+    bool anyNan[ZC];
+#pragma unroll
+    for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; second[k] = 0.f; cnt[k] = 0; anyNan[k] = false; }
+    for (uint32_t j = b; j < e; ++j) {
+        const uint32_t i = a.src[j];
+        float v[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) v[k] = src[koff[k] + i];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) {
+            if (keep<UNDEF>(v[k])) {
+                if (KIND == 0 || KIND == 1) acc[k] = acc[k] + v[k];                        // std::accumulate(.., 0.f)
+                else if (KIND == 3) { if (cnt[k] == 0 || acc[k] < v[k]) acc[k] = v[k]; }   // std::max_element
+                else if (KIND == 4) { if (cnt[k] == 0 || v[k] < acc[k]) acc[k] = v[k]; }   // std::min_element
+                else { if (cnt[k] == 0) acc[k] = v[k]; else second[k] = v[k]; if (isnan(v[k])) anyNan[k] = true; }
+                cnt[k]++;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ZC; ++k) {
+        r[k] = undefined_f();                             // empty bucket, :123-124
+        if (cnt[k] != 0) {
+            if (KIND == 1) r[k] = acc[k] / (float)cnt[k];  // aggrMean: sum / size()
+            else if (KIND == 5) {
+                // a NaN inside an "undef" bucket: see forward_apply_median
+                if (!(UNDEF && anyNan[k])) r[k] = (cnt[k] == 1 || acc[k] > second[k]) ? acc[k] : second[k];
+            } else r[k] = acc[k];
+        }
+    }
+}
+
+// one lane per target cell
 template <int KIND, bool UNDEF, int ZC>
 __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 {
@@ -76,33 +116,11 @@ __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
         size_t koff[ZC];
 #pragma unroll
         for (int k = 0; k < ZC; ++k) koff[k] = (size_t)min((uint32_t)k, z1 - 1 - z) * a.inLayer;
-        float acc[ZC];
-        uint32_t cnt[ZC];
+        float r[ZC];
+        reduce_bucket<KIND, UNDEF, ZC>(a, b, e, src, koff, r);
 #pragma unroll
-        for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; cnt[k] = 0; }
-        for (uint32_t j = b; j < e; ++j) {
-            const uint32_t i = a.src[j];
-            float v[ZC];
-#pragma unroll
-            for (int k = 0; k < ZC; ++k) v[k] = src[koff[k] + i];
-#pragma unroll
-            for (int k = 0; k < ZC; ++k) {
-                if (keep<UNDEF>(v[k])) {
-                    if (KIND == 0 || KIND == 1) acc[k] = acc[k] + v[k];                        // std::accumulate(.., 0.f)
-                    else if (KIND == 3) { if (cnt[k] == 0 || acc[k] < v[k]) acc[k] = v[k]; }   // std::max_element
-                    else { if (cnt[k] == 0 || v[k] < acc[k]) acc[k] = v[k]; }                  // std::min_element
-                    cnt[k]++;
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < ZC; ++k) {
-            if (z + k < z1) {
-                float r = undefined_f();                             // empty bucket, :123-124
-                if (cnt[k] != 0) r = (KIND == 1) ? acc[k] / (float)cnt[k] : acc[k];  // aggrMean: sum / size()
-                __builtin_nontemporal_store(r, a.out + (size_t)(z + k) * a.nOut + t);
-            }
-        }
+        for (int k = 0; k < ZC; ++k)
+            if (z + k < z1) __builtin_nontemporal_store(r[k], a.out + (size_t)(z + k) * a.nOut + t);
     }
 }
 
@@ -341,7 +359,11 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     case Aggregate::Max: u ? launch_kind<3, true>(a, grid, wavePath, stream) : launch_kind<3, false>(a, grid, wavePath, stream); break;
     case Aggregate::Min: u ? launch_kind<4, true>(a, grid, wavePath, stream) : launch_kind<4, false>(a, grid, wavePath, stream); break;
     case Aggregate::Median:
-        if (u) forward_apply_median<true><<<grid, kBlock, 0, stream>>>(a);
+        if (plan.info.maxBucket <= 2 && tuning("FWD_MEDIAN_SHORT", 1) != 0) {  // no bucket holds more than two cells: four slices in flight, no rank counting
+            // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
+            if (u) forward_apply_lane<5, true, 4><<<grid, kBlock, 0, stream>>>(a);
+            else forward_apply_lane<5, false, 4><<<grid, kBlock, 0, stream>>>(a);
+        } else if (u) forward_apply_median<true><<<grid, kBlock, 0, stream>>>(a);
         else forward_apply_median<false><<<grid, kBlock, 0, stream>>>(a);
         break;
     }

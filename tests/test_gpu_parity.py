@@ -911,8 +911,31 @@ def test_release_caches_between_host_calls(fa):
     fa.release_caches()
     fa.release_caches()
     assert cases.same(plan.apply_host(f), want)
-    packed = (f * 10).astype(np.int16)
+    packed = np.clip(np.nan_to_num(f, nan=0.0, posinf=0.0, neginf=0.0) * 10, -30000, 30000).astype(np.int16)
     got = fa.regrid_slice_typed_host(plan, packed[:8], -32767.0)
     fa.release_caches()
     assert cases.same(plan.apply_host(f[:3]), want[:3])
     assert got.dtype == np.int16
+
+
+@pytest.mark.parametrize("method", FORWARD)
+@pytest.mark.parametrize("shape,density", [((150, 120, 64, 50), 0.08), ((150, 120, 63, 51), 0.08), ((300, 200, 100, 80), 0.5), ((200, 150, 40, 36), 2.5)])
+def test_forward_sparse_mappings_and_short_median(fa, monkeypatch, method, shape, density, tuning_build):
+    """Sparse forward mappings (BASELINE configs[3]: most targets stay empty, buckets of one or two cells): the median of
+    buckets of at most two cells runs without rank counting.  Same bits as the oracle and as the rank-counting median; signed
+    zeros and equal values included (the median of two equal-comparing values is the second one)."""
+    inX, inY, outX, outY = shape
+    nz = 9
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=17, density=density)
+    f = cases.field(nz, inY, inX, seed=50 + method, nan_frac=0.05)
+    f[:, ::3, ::2] = np.float32(0.0)
+    f[:, 1::3, 1::2] = np.float32(-0.0)
+    f[:, 2::3, ::5] = np.float32(7.25)
+    want = oracle.forward_interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(want[~np.isnan(want)]))
+    monkeypatch.setenv("FIMEX_AMD_FWD_MEDIAN_SHORT", "0")
+    plain = plan.apply_host(f)
+    assert cases.same(plain, want), cases.describe_mismatch(plain, want)

@@ -851,6 +851,7 @@ struct Fill2dV2Args {
     // check, [4 .. 4 + bands) progress words of the bands whose hand-off crosses workgroups
     unsigned int* sync;
     uint32_t syncStride, groups, nz;
+    uint32_t experiment;
 };
 
 // Flags of the LDS hand-off.  The LDS executes one wave's operations in issue order and is coherent within the CU, so a
@@ -900,6 +901,7 @@ __device__ __forceinline__ float lane_value(float v, int idx)
 // kernel ends and the host call fails with a message -- a wrong counter cannot hang the GPU.
 struct MultiWg {
     uint32_t g, G;            // this workgroup and the number of workgroups of its slice (1: the single-workgroup kernels)
+    uint32_t experiment = 0;  // tuning build: 1 = the producer does not wait for its stores (timing experiment, results invalid)
     unsigned int* flags;      // [bands] progress of the bands whose hand-off crosses workgroups: columns final + 1
     unsigned int* error;      // one word per launch
 };
@@ -1026,6 +1028,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     const uint32_t rowStep = (uint32_t)kRowsPerIt * (nx - 1) * 4u;            // next row group: kRowsPerIt rows down, as many columns back
     float* ringLane = ring + crow * kPitch + ccol;
     auto load_chunk = [&](uint32_t c) {
+        if (kTuningBuild && mg.experiment == 2) return;  // timing experiment: no chunk loads
         if (interior(c)) {
             const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
@@ -1043,6 +1046,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         for (uint32_t it = 0; it < (uint32_t)kCh; ++it) dst[kRowsPerIt * it * kPitch] = stage[it];
     };
     auto flush_chunk = [&](uint32_t c) {
+        if (kTuningBuild && mg.experiment == 3) return;  // timing experiment: no chunk stores
         float v[kCh];
         const float* src = ringLane + ((c * kCh) & kCh);
 #pragma unroll
@@ -1080,19 +1084,22 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         __hip_atomic_store(&hand.produced[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&hand.consumed[slotOut], hand_tag(b, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    auto wait_above = [&](uint32_t k) {  // the stores of band b - 1 up to block k of its last row have completed
-        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], min(64 * k + 64, C + 1) + 1, mg.error); return; }
-        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), mg.error);
+    // The hand-off advances chunk by chunk, not in blocks of 64 columns: band b runs behind band b - 1 by the 63 columns of the
+    // skew plus one or two chunks, and these lags add up over all bands of a sweep -- the critical path of a small batch.
+    auto wait_above = [&](uint32_t cols) {  // the stores of band b - 1 have completed for columns < cols of its last row
+        cols = min(cols, C + 1);
+        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], cols + 1, mg.error); return; }
+        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, cols), mg.error);
     };
-    // block k (columns 64k .. 64k+63) of the row above from the hand-off of band b - 1
-    auto take_above = [&](uint32_t k) -> float {
-        const unsigned int need = hand_tag(b - 1, min(64 * k + 64, C + 1));
+    // columns [xpc, xpc + kCh) of the row above from the LDS hand-off of band b - 1, into lanes (column % 64) of upCur
+    auto take_above = [&](uint32_t xpc, float& upCur) {
+        const unsigned int need = hand_tag(b - 1, min(xpc + kCh, C + 1));
         // a larger band tag means the producer has finished band b - 1 long ago (its data stay in the other parity slot)
         wait_lds_at_least(&hand.produced[slotIn], need, mg.error);
-        const float v = handIn[(64 * k + lane) % kHandW];
+        const float v = handIn[((xpc & ~63u) + lane) % kHandW];
+        if (lane - (xpc & 63u) < (uint32_t)kCh) upCur = v;
         if (lane == 0)
-            lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64));
-        return v;
+            lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, xpc + kCh));
     };
 
     // ---- prologue: chunks 0 and 1 in LDS, chunk 2 in flight; first blocks and mask words.
@@ -1102,14 +1109,16 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     load_chunk(1);
     commit_chunk(1);
     load_chunk(2);
-    float upCur, upLd = 0.f;
-    if (b == 0) upCur = load_block(0, 0);
-    else if (inGlobal) { wait_above(0); upCur = load_block(0, 0); }
-    else upCur = take_above(0);
-    if ((b == 0 || inGlobal) && ((2 * kCh) & 63) == 0) {  // the event that would prefetch block 1 two chunks ahead is "chunk 0", which has none
-        if (inGlobal) wait_above((2 * kCh) >> 6);
-        upLd = load_block(0, (2 * kCh) >> 6);
-    }
+    // row above: lanes (column % 64) of upCur hold the chunk in work; from global memory (row 0, or a band whose predecessor
+    // hands over through global memory) the next chunk's block is requested one event ahead into upLd
+    float upCur = 0.f, upLd = 0.f;
+    const bool fromGlobal = b == 0 || inGlobal;
+    if (fromGlobal) {
+        if (inGlobal) wait_above(kCh);
+        upCur = load_block(0, 0);
+        if (inGlobal) wait_above(2 * kCh);
+        upLd = load_block(0, kCh >> 6);
+    } else take_above(0, upCur);
     float downA = load_block(nrow + 1, 0), downB = downA, downLd = 0.f;  // current / next (landed) / in flight
     uint32_t downIssued = 0;
     bool downLdValid = false;
@@ -1123,7 +1132,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
         if (c > 0) {
             // ---- event at the start of chunk c
             if (outGlobal && xpc > L) {  // stores of the previous event (chunk c - 2) have landed: columns < 16 (c - 1) - L of the last row
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(kTuningBuild && mg.experiment == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0 && xpc - kCh > L) {
                     if (MULTI) __hip_atomic_store(&mg.flags[b], xpc - kCh - L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - kCh - L));
@@ -1147,10 +1156,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 downLdValid = true;
             }
             // row above: lane 0 is at column x'
-            if ((xpc & 63) == 0 && (b == 0 || inGlobal)) upCur = upLd;  // from global, requested two chunks ago
-            if ((b == 0 || inGlobal) && ((xpc + 2 * kCh) & 63) == 0) {
-                if (inGlobal) wait_above((xpc + 2 * kCh) >> 6);
-                upLd = load_block(0, (xpc + 2 * kCh) >> 6);
+            if (fromGlobal) {
+                if (lane - (xpc & 63u) < (uint32_t)kCh) upCur = upLd;  // this chunk's columns, requested one event ago
+                if (inGlobal) wait_above(xpc + 2 * kCh);
+                upLd = load_block(0, (xpc + kCh) >> 6);
             }
             flush_chunk(c - 1);      // results of the chunk just finished -> global (never waited for)
             commit_chunk(c + 1);     // loaded one event ago, into the ring slot the flush has just read
@@ -1168,7 +1177,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                     }
                 }
             }
-            if ((xpc & 63) == 0 && !(b == 0 || inGlobal)) upCur = take_above(xpc >> 6);
+            if (!fromGlobal) take_above(xpc, upCur);
             load_chunk(c + 2);       // consumed at the next event
         }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCh - 1, xpEnd);
@@ -1189,19 +1198,38 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 const float vd = (switches && j >= kSwitch) ? fromB : fromA;
                 if (lane < (uint32_t)kCh) ringVirtual[(xpc + 1 + j) & (kRingW - 1)] = vd;
             }
+            // Everything a group of 16 steps reads from the ring is read first -- a position is read (as "right" / "down" of
+            // the step before) strictly before the step that rewrites it, so the values are the ones the interleaved order saw
+            // -- and the results are written after the group's last step: the dependent chain of a step (the lane above's
+            // previous result -> sum -> error -> result) then runs on registers, DPP and readlane alone, with no LDS latency
+            // in it.  The chain is what a band's time consists of, and the bands' lags add up to a sweep's critical path.
+            // (Workgroups of 16 waves have 128 registers per lane and four waves per SIMD to cover the latency: interleaved.)
+            constexpr bool kPreload = WAVES <= 8;
+            constexpr int kGroup = kPreload ? 16 : 1;
 #pragma unroll
-            for (int k = 0; k < kCh; ++k) {
-                const float right = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
-                const float down = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
-                const float center = prevRight;
-                const float up = lane_from_above_or(prevRes, lane_value(upCur, (int)(up0 + k)));
-                const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
-                const float e = sor_error(((right + prevRes) + down) + up, center);  // interpolation.c:1332
-                const float res = center + e * wv;                                                           // :1333
-                rc[k] = res;
-                prevRes = res;
-                if (check && (fabsf(e * wv) > crtest)) bad = 1;                                              // :1349
-                prevRight = right;
+            for (int g0 = 0; g0 < kCh; g0 += kGroup) {
+                float R[kGroup], D[kGroup], out[kGroup];
+#pragma unroll
+                for (int q = 0; q < kGroup; ++q) {
+                    const int k = g0 + q;
+                    R[q] = (k < kCh - 1) ? rc[k + 1] : ringRow[rNext];
+                    D[q] = (k < kCh - 1) ? rb[k + 1] : ringBelow[rNext];
+                }
+#pragma unroll
+                for (int q = 0; q < kGroup; ++q) {
+                    const int k = g0 + q;
+                    const float center = prevRight;
+                    const float up = lane_from_above_or(prevRes, lane_value(upCur, (int)(up0 + k)));
+                    const float wv = ((mw >> (sh0 + k)) & 1u) ? wInt : wZero;
+                    const float e = sor_error(((R[q] + prevRes) + D[q]) + up, center);  // interpolation.c:1332
+                    const float res = center + e * wv;                                                           // :1333
+                    out[q] = res;
+                    prevRes = res;
+                    if (check && (fabsf(e * wv) > crtest)) bad = 1;                                              // :1349
+                    prevRight = R[q];
+                }
+#pragma unroll
+                for (int q = 0; q < kGroup; ++q) rc[g0 + q] = out[q];
             }
             if (switches) downA = downB;
             if (lane < (uint32_t)kCh) handOut[(xpc + lane - L) % kHandW] = ring[L * kPitch + ((xpc + lane) & (kRingW - 1))];
@@ -1315,7 +1343,7 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v2(Fill2dV2Args a
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
     const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
     float* ring = rings + wave * (kWave + 1) * kPitch;
-    const MultiWg single{0u, 1u, nullptr, a.error};
+    const MultiWg single{0u, 1u, 0u, nullptr, a.error};
     for (unsigned long long n = 0; n < a.maxLoop; ++n) {
         const bool check = (n < (a.maxLoop - 5)) && (n % 10 == 0);
         int bad = 0;
@@ -1374,7 +1402,8 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v3(Fill2dV2Args a
     unsigned char* mbRight = mbLeft + ny;
     SliceStats* st = a.stats + slice;
     unsigned int* sync = a.sync + (size_t)slice * a.syncStride;
-    const MultiWg mg{g, G, sync + 4, a.error};
+    MultiWg mg{g, G, 0u, sync + 4, a.error};
+    mg.experiment = a.experiment;
     const uint32_t wave = threadIdx.x / kWave;
     if (st->skip) return;  // :1266-1269 (the same for every workgroup of the slice)
     const double crit = st->meanAbsDev;
@@ -1706,9 +1735,10 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     }
     // every 16th boundary goes through global memory (see fill2d_band): values from the flushed row, weights from the
     // D mask and this sweep's U words of that row (skew 63), which the producing band stores at every event
-    auto wait_above = [&](uint32_t k) {
-        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], min(64 * k + 64, C + 1) + 1, error); return; }
-        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), error);
+    auto wait_above = [&](uint32_t cols) {  // chunk by chunk, see fill2d_band
+        cols = min(cols, C + 1);
+        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], cols + 1, error); return; }
+        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, cols), error);
     };
     auto load_wblock_above = [&](uint32_t k) -> float {
         const uint32_t xs = min(64 * k + lane, nx - 1) + (kWave - 1);
@@ -1717,13 +1747,15 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                                  : uNew[(size_t)(y0 - 1) * mws + (xs >> 5)];
         return ((d >> (xs & 31)) & 1u) ? swf : (float)((u >> (xs & 31)) & 1u);
     };
-    auto take_above = [&](uint32_t k, float& fv, float& wv) {
-        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(64 * k + 64, C + 1)), error);
-        fv = handIn[(64 * k + lane) % kHandWC];
-        const unsigned int code = handInW[(64 * k + lane) % kHandWC];
-        wv = (code == 2u) ? swf : (float)code;
+    // columns [xpc, xpc + kCreepCh) of the row above (values and weights) into lanes (column % 64)
+    auto take_above = [&](uint32_t xpc, float& fv, float& wv) {
+        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, min(xpc + kCreepCh, C + 1)), error);
+        const uint32_t col = (xpc & ~63u) + lane;
+        const float v = handIn[col % kHandWC];
+        const unsigned int code = handInW[col % kHandWC];
+        if (lane - (xpc & 63u) < (uint32_t)kCreepCh) { fv = v; wv = (code == 2u) ? swf : (float)code; }
         if (lane == 0)
-            lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, 64 * k + 64));
+            lds_publish(&hand.consumed[slotIn], hand_tag(b - 1, xpc + kCreepCh));
     };
 
     load_chunk(0);
@@ -1731,16 +1763,16 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
     load_chunk(1);
     commit_chunk(1);
     load_chunk(2);
-    float upCur, upWCur, upLd = 0.f, upWLd = 0.f;
-    if (b == 0) { upCur = load_block(0, 0); upWCur = load_wblock(0, 0); }
-    else if (inGlobal) { wait_above(0); upCur = load_block(0, 0); upWCur = load_wblock_above(0); }
-    else take_above(0, upCur, upWCur);
-    if ((b == 0 || inGlobal) && ((2 * kCreepCh) & 63) == 0) {  // see fill2d_band
-        const uint32_t k = (2 * kCreepCh) >> 6;
-        if (inGlobal) wait_above(k);
-        upLd = load_block(0, k);
-        upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
-    }
+    float upCur = 0.f, upWCur = 0.f, upLd = 0.f, upWLd = 0.f;
+    const bool fromGlobal = b == 0 || inGlobal;
+    if (fromGlobal) {  // see fill2d_band: the chunk in work in lanes (column % 64), the next chunk's block one event ahead
+        if (inGlobal) wait_above(kCreepCh);
+        upCur = load_block(0, 0);
+        upWCur = inGlobal ? load_wblock_above(0) : load_wblock(0, 0);
+        if (inGlobal) wait_above(2 * kCreepCh);
+        upLd = load_block(0, kCreepCh >> 6);
+        upWLd = inGlobal ? load_wblock_above(kCreepCh >> 6) : load_wblock(0, kCreepCh >> 6);
+    } else take_above(0, upCur, upWCur);
     const uint32_t yBelow = y0 + nrow;
     float downA = load_block(nrow + 1, 0), downB = downA, downLd = 0.f;
     float downWA = load_wblock(yBelow, 0), downWB = downWA, downWLd = 0.f;
@@ -1788,10 +1820,10 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 downWLd = load_wblock(yBelow, downIssued);
                 downLdValid = true;
             }
-            if ((xpc & 63) == 0 && (b == 0 || inGlobal)) { upCur = upLd; upWCur = upWLd; }
-            if ((b == 0 || inGlobal) && ((xpc + 2 * kCreepCh) & 63) == 0) {
-                const uint32_t k = (xpc + 2 * kCreepCh) >> 6;
-                if (inGlobal) wait_above(k);
+            if (fromGlobal) {
+                if (lane - (xpc & 63u) < (uint32_t)kCreepCh) { upCur = upLd; upWCur = upWLd; }  // this chunk's columns, requested one event ago
+                const uint32_t k = (xpc + kCreepCh) >> 6;
+                if (inGlobal) wait_above(xpc + 2 * kCreepCh);
                 upLd = load_block(0, k);
                 upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
             }
@@ -1810,7 +1842,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                     }
                 }
             }
-            if ((xpc & 63) == 0 && !(b == 0 || inGlobal)) take_above(xpc >> 6, upCur, upWCur);
+            if (!fromGlobal) take_above(xpc, upCur, upWCur);
             load_chunk(c + 2);
         }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCreepCh - 1, xpEnd);
@@ -1983,7 +2015,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
         uint32_t* uNew = maskU + (size_t)(l % a.gens) * maskWords;
         int mine = 0;
         for (uint32_t b = wave; b < nBands; b += kCreepWaves)
-            creep_band<false>(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine, MultiWg{0u, 1u, nullptr, a.error});
+            creep_band<false>(f, maskD, uOld, uHist, uNew, ring, hand, b, nx, ny, mws, swf, a.skipIdle != 0, mine, MultiWg{0u, 1u, 0u, nullptr, a.error});
         changedInLoop = __syncthreads_or(mine);
     }
     // borders (:1464-1489): undefined border cells have r = 0 < repeat in every round, defined ones never change
@@ -2053,7 +2085,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v3(CreepV2Args
     uint32_t* maskU = a.maskU + (size_t)slice * a.gens * maskWords;
     SliceStats* st = a.stats + slice;
     unsigned int* sync = a.sync + (size_t)slice * a.syncStride;
-    const MultiWg mg{g, G, sync + 4, a.error};
+    const MultiWg mg{g, G, 0u, sync + 4, a.error};
     const uint32_t wave = threadIdx.x / kWave;
     if (st->skip) return;  // :1384-1386, :1515
     const unsigned long long nDef = total - st->nUndef;
@@ -2208,6 +2240,7 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
             sync.allocate(nz * a.syncStride);
             FA_HIP(hipMemsetAsync(sync.get(), 0, sync.bytes(), stream));
             a.sync = sync.get();
+            a.experiment = (uint32_t)tuning("FILL_EXPERIMENT", 0);
             // more LDS than half a CU has, so that no two of these workgroups share a CU (and its SIMDs)
             const size_t mlds = std::max<size_t>((size_t)mwaves * (kWave + 1) * (2 * mch + 1) * sizeof(float) + (size_t)mwaves * 2 * kHandW * sizeof(float) +
                                                      (size_t)mwaves * 4 * sizeof(unsigned int), 84 * 1024);

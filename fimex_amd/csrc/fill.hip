@@ -852,6 +852,7 @@ struct Fill2dV2Args {
     unsigned int* sync;
     uint32_t syncStride, groups, nz;
     uint32_t experiment;
+    unsigned long long* prof;
 };
 
 // Flags of the LDS hand-off.  The LDS executes one wave's operations in issue order and is coherent within the CU, so a
@@ -904,6 +905,7 @@ struct MultiWg {
     uint32_t experiment = 0;  // tuning build: 1 = the producer does not wait for its stores (timing experiment, results invalid)
     unsigned int* flags;      // [bands] progress of the bands whose hand-off crosses workgroups: columns final + 1
     unsigned int* error;      // one word per launch
+    unsigned long long* prof = nullptr;  // tuning build, experiment 4: cycles summed over bands: [0] events, [1] steps, [2] bands
 };
 constexpr unsigned int kSpinCapLds = 1u << 24;     // ~1 s of polling LDS
 constexpr unsigned int kSpinCapGlobal = 1u << 21;  // ~1 s of polling memory
@@ -982,6 +984,11 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     FILL_GEOMETRY(CH, WAVES);
     constexpr bool check = CHECK;
     using rsrc_t = __amdgpu_buffer_rsrc_t;
+    // The band is the same for the whole wave, but it derives from threadIdx: said explicitly, the buffer descriptor of the
+    // band's rows and every "is this the band that hands over through global memory" test stay in scalar registers.  Left to
+    // the compiler, each of the 32 buffer loads and stores of an event sat in a loop over the lanes' (identical) descriptors
+    // and each store behind a divergent branch: 7 000 cycles per event against 1 900 for the sixteen steps between two events.
+    b = __builtin_amdgcn_readfirstlane(b);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t y0 = 1 + kWave * b;
     const uint32_t nrow = min((uint32_t)kWave, (ny - 1) - y0);  // rows y0 .. y0 + nrow - 1 <= ny - 2
@@ -1001,6 +1008,8 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     // (loads return 0, stores are dropped), so every memory instruction is issued unconditionally
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f + (size_t)(y0 - 1) * nx, 0, (nrow + 2) * nx * 4u, 0x00020000);
     const uint32_t kOob = 0xFFFFFFFFu;
+    const bool prof = kTuningBuild && mg.experiment == 4 && mg.prof != nullptr;
+    unsigned long long tWait = 0, tFlush = 0;
     // Every W-th boundary (band W-1 -> W, 2W-1 -> 2W, ...) goes through global memory: in one workgroup the wave of band b + 1
     // is still busy with band b + 1 - W there (a bounded LDS window would close a cycle of waiting waves on wide grids), with
     // several workgroups per slice (MULTI) band b + 1 belongs to the next workgroup.  The producer's flush already writes the
@@ -1045,12 +1054,19 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
 #pragma unroll
         for (uint32_t it = 0; it < (uint32_t)kCh; ++it) dst[kRowsPerIt * it * kPitch] = stage[it];
     };
-    auto flush_chunk = [&](uint32_t c) {
-        if (kTuningBuild && mg.experiment == 3) return;  // timing experiment: no chunk stores
-        float v[kCh];
+    // The results of a finished chunk leave in two steps: out of the ring into registers (before the ring slot is refilled),
+    // and to global memory AFTER the event's loads have been issued.  Vector-memory operations complete in issue order: a load
+    // that sits behind sixteen stores is not counted as done before they are, so the wait for the next chunk's data was a wait
+    // for this chunk's stores -- 3-4 us per event, which set the pace of every band (measured with the tuning build's cycle
+    // counters: 8 400 cycles per event against 1 900 for the sixteen steps between two events).
+    float v[kCh];
+    auto flush_read = [&](uint32_t c) {
         const float* src = ringLane + ((c * kCh) & kCh);
 #pragma unroll
         for (uint32_t it = 0; it < (uint32_t)kCh; ++it) v[it] = src[kRowsPerIt * it * kPitch];
+    };
+    auto flush_store = [&](uint32_t c) {
+        if (kTuningBuild && mg.experiment == 3) return;  // timing experiment: no chunk stores
         if (interior(c)) {
             const uint32_t s0 = c * kCh * 4u;
 #pragma unroll
@@ -1088,14 +1104,18 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     // skew plus one or two chunks, and these lags add up over all bands of a sweep -- the critical path of a small batch.
     auto wait_above = [&](uint32_t cols) {  // the stores of band b - 1 have completed for columns < cols of its last row
         cols = min(cols, C + 1);
-        if (MULTI) { wait_global_at_least(&mg.flags[b - 1], cols + 1, mg.error); return; }
-        wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, cols), mg.error);
+        const unsigned long long t0 = prof ? clock64() : 0;
+        if (MULTI) wait_global_at_least(&mg.flags[b - 1], cols + 1, mg.error);
+        else wait_lds_at_least(&hand.produced[slotIn], hand_tag(b - 1, cols), mg.error);
+        if (prof) tWait += clock64() - t0;
     };
     // columns [xpc, xpc + kCh) of the row above from the LDS hand-off of band b - 1, into lanes (column % 64) of upCur
     auto take_above = [&](uint32_t xpc, float& upCur) {
         const unsigned int need = hand_tag(b - 1, min(xpc + kCh, C + 1));
         // a larger band tag means the producer has finished band b - 1 long ago (its data stay in the other parity slot)
+        const unsigned long long t0 = prof ? clock64() : 0;
         wait_lds_at_least(&hand.produced[slotIn], need, mg.error);
+        if (prof) tWait += clock64() - t0;
         const float v = handIn[((xpc & ~63u) + lane) % kHandW];
         if (lane - (xpc & 63u) < (uint32_t)kCh) upCur = v;
         if (lane == 0)
@@ -1127,8 +1147,10 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     float prevRight = ringRow[1];  // lane 0 is at column 1 in the first step: its centre is skewed column 1
 
     const uint32_t nChunks = xpEnd / kCh + 1;
+    unsigned long long tEvents = 0, tSteps = 0, tMark = prof ? clock64() : 0;
     for (uint32_t c = 0; c < nChunks; ++c) {
         const uint32_t xpc = c * kCh;
+        if (prof) { const unsigned long long t = clock64(); tSteps += t - tMark; tMark = t; }
         if (c > 0) {
             // ---- event at the start of chunk c
             if (outGlobal && xpc > L) {  // stores of the previous event (chunk c - 2) have landed: columns < 16 (c - 1) - L of the last row
@@ -1161,7 +1183,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 if (inGlobal) wait_above(xpc + 2 * kCh);
                 upLd = load_block(0, (xpc + kCh) >> 6);
             }
-            flush_chunk(c - 1);      // results of the chunk just finished -> global (never waited for)
+            flush_read(c - 1);       // results of the chunk just finished: ring -> registers
             commit_chunk(c + 1);     // loaded one event ago, into the ring slot the flush has just read
             // publish how far the last row has got, and do not run more than the hand-off window ahead of the band below
             if (xpc > L && !outGlobal) {
@@ -1169,17 +1191,21 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                     lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
                 if (hasBelow) {
                     const unsigned int limit = xpc + kCh - L;  // columns < limit are written during this chunk
+                    const unsigned long long t0 = prof ? clock64() : 0;
                     for (unsigned int it = 0;; ++it) {
                         const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
                         if (limit <= (cns & 0x7FFFFu) + kHandW) break;
                         __builtin_amdgcn_s_sleep(1);
                         if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(mg.error))) { fail_launch(mg.error, 3); break; }
                     }
+                    if (prof) tFlush += clock64() - t0;  // (window waits, counted apart)
                 }
             }
             if (!fromGlobal) take_above(xpc, upCur);
             load_chunk(c + 2);       // consumed at the next event
+            flush_store(c - 1);      // registers -> global, behind the loads (never waited for)
         }
+        if (prof) { const unsigned long long t = clock64(); tEvents += t - tMark; tMark = t; }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCh - 1, xpEnd);
         if (interior(c) && xpc > (uint32_t)kWave) {
             // ---- every lane is at a cell the sweep updates, at x >= 2: no range tests, "left" is the previous result
@@ -1305,7 +1331,16 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             prevRight = right;
         }
     }
-    flush_chunk(nChunks - 1);
+    if (prof && lane == 0) {
+        atomicAdd(&mg.prof[0], tEvents);
+        atomicAdd(&mg.prof[1], tSteps + (clock64() - tMark));
+        atomicAdd(&mg.prof[2], 1ull);
+        atomicAdd(&mg.prof[3], tWait);
+        atomicAdd(&mg.prof[4], tFlush);
+        if (b == 0) { atomicAdd(&mg.prof[5], tEvents); atomicAdd(&mg.prof[6], tSteps); atomicAdd(&mg.prof[7], 1ull); }
+    }
+    flush_read(nChunks - 1);
+    flush_store(nChunks - 1);
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
         if (MULTI && outGlobal) __hip_atomic_store(&mg.flags[b], C + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1404,6 +1439,7 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v3(Fill2dV2Args a
     unsigned int* sync = a.sync + (size_t)slice * a.syncStride;
     MultiWg mg{g, G, 0u, sync + 4, a.error};
     mg.experiment = a.experiment;
+    mg.prof = a.prof;
     const uint32_t wave = threadIdx.x / kWave;
     if (st->skip) return;  // :1266-1269 (the same for every workgroup of the slice)
     const double crit = st->meanAbsDev;
@@ -1630,6 +1666,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
 {
     unsigned int* const error = mg.error;
     using rsrc_t = __amdgpu_buffer_rsrc_t;
+    b = __builtin_amdgcn_readfirstlane(b);  // wave-uniform, see fill2d_band
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t y0 = 1 + kWave * b;
     const uint32_t nrow = min((uint32_t)kWave, (ny - 1) - y0);
@@ -1684,11 +1721,14 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
 #pragma unroll
         for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it) dst[kCreepRowsPerIt * it * kCreepPitch] = stage[it];
     };
-    auto flush_chunk = [&](uint32_t c) {
-        float v[kCreepCh];
+    // ring -> registers before the slot is refilled, registers -> global behind the event's loads (see fill2d_band)
+    float v[kCreepCh];
+    auto flush_read = [&](uint32_t c) {
         const float* src = ringLane + ((c * kCreepCh) & kCreepCh);
 #pragma unroll
         for (uint32_t it = 0; it < (uint32_t)kCreepCh; ++it) v[it] = src[kCreepRowsPerIt * it * kCreepPitch];
+    };
+    auto flush_store = [&](uint32_t c) {
         if (interior(c)) {
             const uint32_t s0 = c * kCreepCh * 4u;
 #pragma unroll
@@ -1827,7 +1867,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 upLd = load_block(0, k);
                 upWLd = inGlobal ? load_wblock_above(k) : load_wblock(0, k);
             }
-            flush_chunk(c - 1);
+            flush_read(c - 1);
             commit_chunk(c + 1);
             if (xpc > L && !outGlobal) {
                 if (lane == 0)
@@ -1844,6 +1884,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             }
             if (!fromGlobal) take_above(xpc, upCur, upWCur);
             load_chunk(c + 2);
+            flush_store(c - 1);
         }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCreepCh - 1, xpEnd);
         // A chunk in which no row has a cell that may still change (undefined on entry and not yet updated `repeat` times:
@@ -1968,7 +2009,8 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             prevRight = right;
         }
     }
-    flush_chunk(nChunks - 1);
+    flush_read(nChunks - 1);
+    flush_store(nChunks - 1);
     if (rowValid) store_u((nChunks - 1) / kCreepChunksPerWord, un);
     if (outGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
@@ -2241,6 +2283,23 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
             FA_HIP(hipMemsetAsync(sync.get(), 0, sync.bytes(), stream));
             a.sync = sync.get();
             a.experiment = (uint32_t)tuning("FILL_EXPERIMENT", 0);
+            DeviceArray<unsigned long long> prof(8);
+            FA_HIP(hipMemsetAsync(prof.get(), 0, 8 * sizeof(unsigned long long), stream));
+            a.prof = prof.get();
+            struct ProfDump {
+                DeviceArray<unsigned long long>& p; hipStream_t st; uint32_t on;
+                ~ProfDump() {
+                    if (on != 4) return;
+                    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    (void)hipStreamSynchronize(st);
+                    (void)hipMemcpy(h, p.get(), sizeof(h), hipMemcpyDeviceToHost);
+                    std::fprintf(stderr, "fill2d profile: bands %llu, cycles per band: events %.0f (waiting for the band above %.0f, for the band below %.0f), steps %.0f\n",
+                                 h[2], h[2] ? (double)h[0] / h[2] : 0.0, h[2] ? (double)h[3] / h[2] : 0.0, h[2] ? (double)h[4] / h[2] : 0.0,
+                                 h[2] ? (double)h[1] / h[2] : 0.0);
+                    std::fprintf(stderr, "fill2d profile: band 0 (waits for nobody above): events %.0f, steps %.0f cycles per sweep\n", h[7] ? (double)h[5] / h[7] : 0.0,
+                                 h[7] ? (double)h[6] / h[7] : 0.0);
+                }
+            } profDump{prof, stream, a.experiment};
             // more LDS than half a CU has, so that no two of these workgroups share a CU (and its SIMDs)
             const size_t mlds = std::max<size_t>((size_t)mwaves * (kWave + 1) * (2 * mch + 1) * sizeof(float) + (size_t)mwaves * 2 * kHandW * sizeof(float) +
                                                      (size_t)mwaves * 4 * sizeof(unsigned int), 84 * 1024);

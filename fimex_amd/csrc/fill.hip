@@ -989,6 +989,18 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     // the compiler, each of the 32 buffer loads and stores of an event sat in a loop over the lanes' (identical) descriptors
     // and each store behind a divergent branch: 7 000 cycles per event against 1 900 for the sixteen steps between two events.
     b = __builtin_amdgcn_readfirstlane(b);
+    {   // (where this function is not inlined its arguments arrive in vector registers: the same for the slice's pointers)
+        auto uniform = [](auto* ptr) {
+            const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<decltype(ptr)>(((uint64_t)hi << 32) | lo);
+        };
+        f = uniform(f);
+        maskS = uniform(maskS);
+        nx = __builtin_amdgcn_readfirstlane(nx);
+        ny = __builtin_amdgcn_readfirstlane(ny);
+        mws = __builtin_amdgcn_readfirstlane(mws);
+    }
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t y0 = 1 + kWave * b;
     const uint32_t nrow = min((uint32_t)kWave, (ny - 1) - y0);  // rows y0 .. y0 + nrow - 1 <= ny - 2

@@ -148,7 +148,7 @@ struct Staged2Args {
     uint32_t nOut;
     uint32_t nz;
     uint32_t zStart[kMaxZChunks + 1];  // slices [zStart[c], zStart[c + 1]) belong to z chunk c = blockIdx.y
-    uint32_t ldsFloats;  // floats of the slice ring
+    uint32_t slotChunks;  // 16-byte chunks of one slot of the slice ring (a multiple of 64: whole wave instructions)
     uint32_t flags;      // tuning build only: 1 no source loads, 2 no result stores
 };
 
@@ -183,7 +183,17 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
         gOff[j] = (c < T.nChunks) ? a.chunkOff[T.chunkBase + c] * 4u : 0xFFFFFFFFu;  // ~0u: dropped by the bounds check (zeros)
     }
     const uint32_t un = (T.nChunks + NT - 1) / NT;
-    const uint32_t slotFloats = (a.ldsFloats / DEPTH) & ~3u;  // DEPTH slots, each holds the largest tile of the plan
+    // DEPTH slots, each holds the largest tile of the plan, then 1 KiB that is never read.  A lane without a chunk carries an
+    // offset beyond the slice and the DMA writes ZEROS for it (scripts/calib/dma_oob.hip): inside the slot that is unused
+    // space, but a slot is not a whole number of NT chunks, and the last wave instructions of a full tile would run past
+    // its end into the next slot -- the slice being interpolated.  Such an instruction (whole: slots are multiples of 64
+    // chunks) is pointed at the spare KiB instead of being left out, so every wave issues the same number of them.
+    const uint32_t slotFloats = a.slotChunks * 4u;
+    float* const spare = smem + DEPTH * slotFloats;
+    auto dma_dst = [&](uint32_t sl, int j) {
+        const uint32_t c = waveChunk + (uint32_t)j * NT;
+        return c < a.slotChunks ? smem + sl * slotFloats + c * 4u : spare;
+    };
     const uint32_t inRecords = (kTuningBuild && (a.flags & 1)) ? 0u : a.inBytes;
 
     // prologue: DEPTH - 1 slices in flight (issued here, before the per-output plan is loaded)
@@ -191,7 +201,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
         const rsrc_t rs = make_rsrc(inBase + (size_t)(z0 + i) * a.inBytes, inRecords);
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
-            if ((uint32_t)j < un) dma16(rs, smem + i * slotFloats + (waveChunk + j * NT) * 4, gOff[j]);
+            if ((uint32_t)j < un) dma16(rs, dma_dst(i, j), gOff[j]);
     }
     // ---- per-lane plan: outputs e = threadIdx.x + k * NT of the tile (a wave covers 64 consecutive cells of one row)
     uint32_t cellOff[PER];
@@ -336,9 +346,8 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
             if (more) {  // into the slot slice i - 1 has left
                 const uint32_t sl = (slot + DEPTH - 1 >= (uint32_t)DEPTH) ? slot - 1 : slot + DEPTH - 1;
                 const rsrc_t rs = make_rsrc(inBase + (size_t)(z + DEPTH - 1) * a.inBytes, inRecords);
-                float* dst = smem + sl * slotFloats;
 #pragma unroll
-                for (int j = 0; j < UN; ++j) dma16(rs, dst + (waveChunk + j * NT) * 4, gOff[j]);
+                for (int j = 0; j < UN; ++j) dma16(rs, dma_dst(sl, j), gOff[j]);
             }
             const char* curb = reinterpret_cast<const char*>(smem + slot * slotFloats);
             const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
@@ -425,6 +434,14 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
     }
 }
 
+constexpr uint32_t kSpareBytes = 1024;  // one wave instruction of LDS-DMA behind the ring (see staged_apply2)
+
+// chunks of one slot: the workgroup's LDS less the spare KiB, in `depth` equal slots of whole wave instructions
+inline uint32_t slot_chunks(uint32_t ldsBytes, uint32_t depth)
+{
+    return ((ldsBytes - kSpareBytes) / depth / 16u) & ~63u;
+}
+
 struct Shape2 {
     int nt, per, kmax;
     uint32_t depth;
@@ -466,8 +483,7 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
     const uint32_t tileH = sh.tileH;
     const uint32_t nBands = (uint32_t)ceil_div(outY, tileH);
     // the ring holds `depth` slots, each large enough for any tile (chunks rounded up to whole wave instructions)
-    uint32_t cap = (sh.ldsBytes / sh.depth - 16) / 16;
-    cap = std::min<uint32_t>(cap & ~63u, (uint32_t)sh.kmax * sh.nt);
+    uint32_t cap = std::min<uint32_t>(slot_chunks(sh.ldsBytes, sh.depth), (uint32_t)sh.kmax * sh.nt);
     cap = std::min<uint32_t>(cap, 16383u);  // 16-bit LDS offsets in floats
     const uint32_t step = sh.tileW >= 128 ? 64u : 32u;  // tile widths are multiples of this (a wave stores 64 consecutive cells)
     // Tiles: every tile row starts as tiles of the widest shape.  A tile that does not fit (too many chunks for a slot, too
@@ -625,6 +641,7 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     const int ldsDefault = nt == 256 ? 52 : (nt == 512 ? 79 : 159);
     sh.ldsBytes = (uint32_t)tuning("STAGE2_LDS_KB", ldsDefault) * 1024u;
     if (sh.ldsBytes > 160u * 1024u - 64u) sh.ldsBytes = 160u * 1024u - 64u;
+    if (sh.ldsBytes < 16u * 1024u) return false;
     sh.depth = tuning("STAGE2_DEPTH", 2) == 3 ? 3u : 2u;  // slices of the ring: one or two in flight while one is interpolated
     // stripes of 8 tile rows per XCD: the bilinear launch fetches 10.2 instead of 11.1 GB (vertical neighbours meet in one L2) at
     // the same or a slightly shorter time; the 1 x 1 stencil shares nothing vertically and runs 3 % faster with single rows
@@ -677,7 +694,7 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
         z += size;
     }
     a.zStart[nChunks] = (uint32_t)nz;
-    a.ldsFloats = s.ldsBytes / 4;
+    a.slotChunks = slot_chunks(s.ldsBytes, s.depth);
     a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0);
     const dim3 grid(s.gridX, nChunks, 1);
     switch (plan.kind) {

@@ -148,6 +148,7 @@ struct Staged2Args {
     uint32_t nOut;
     uint32_t nz;
     uint32_t zStart[kMaxZChunks + 1];  // slices [zStart[c], zStart[c + 1]) belong to z chunk c = blockIdx.y
+    uint32_t nZChunks;    // > 0: flat grid, the z chunks of a tile are consecutive workgroups of one XCD (see launch_staged2_apply)
     uint32_t slotChunks;  // 16-byte chunks of one slot of the slice ring (a multiple of 64: whole wave instructions)
     uint32_t flags;      // tuning build only: 1 no source loads, 2 no result stores
 };
@@ -161,11 +162,17 @@ template <int STENCIL, int NT, int PER, int KMAX, bool FAST = false, int DEPTH =
 __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const uint32_t tile = a.order[blockIdx.x];
+    uint32_t slot0 = blockIdx.x, zc = blockIdx.y;
+    if (a.nZChunks != 0) {  // workgroup s runs on XCD s % 8; the k-th workgroup of an XCD is z chunk k % n of the XCD's tile k / n
+        const uint32_t k = blockIdx.x / kXcds;
+        zc = k % a.nZChunks;
+        slot0 = (k / a.nZChunks) * kXcds + blockIdx.x % kXcds;
+    }
+    const uint32_t tile = a.order[slot0];
     if (tile == 0xFFFFFFFFu) return;
     const StagedTile T = a.tiles[tile];
-    const uint32_t z0 = a.zStart[blockIdx.y];
-    const uint32_t z1 = a.zStart[blockIdx.y + 1];
+    const uint32_t z0 = a.zStart[zc];
+    const uint32_t z1 = a.zStart[zc + 1];
     const uint32_t nzl = z1 - z0;
 
     const uint32_t outBytes = a.nOut * 4u;
@@ -643,9 +650,10 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     if (sh.ldsBytes > 160u * 1024u - 64u) sh.ldsBytes = 160u * 1024u - 64u;
     if (sh.ldsBytes < 16u * 1024u) return false;
     sh.depth = tuning("STAGE2_DEPTH", 2) == 3 ? 3u : 2u;  // slices of the ring: one or two in flight while one is interpolated
-    // stripes of 8 tile rows per XCD: the bilinear launch fetches 10.2 instead of 11.1 GB (vertical neighbours meet in one L2) at
-    // the same or a slightly shorter time; the 1 x 1 stencil shares nothing vertically and runs 3 % faster with single rows
-    const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", plan.kind == PlanKind::Bilinear ? 8 : 1));
+    // tile rows go to the XCDs one by one (row r to XCD r % 8): with the tile-major launch order the eight XCDs then work on eight
+    // neighbouring tile rows at any time.  (With the chunk-major order stripes of 8 rows per XCD fetched 10.2 instead of 11.1 GB for
+    // the bilinear launch at the same time; with the tile-major order stripes of 2, 4 or 8 rows lose 3-6 %.)
+    const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", 1));
     switch (plan.kind) {
     case PlanKind::Nearest: return build_shape<1>(plan, d_px, d_py, stream, sh, stripe);
     case PlanKind::Bilinear: return build_shape<2>(plan, d_px, d_py, stream, sh, stripe);
@@ -677,14 +685,28 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.inBytes = (uint32_t)(plan.inX * plan.inY * 4);
     a.nOut = (uint32_t)(plan.outX * plan.outY);
     a.nz = (uint32_t)nz;
-    // z chunks: workgroups are handed out in order (all tiles of chunk 0, then chunk 1, ...), a CU picks the next one when
-    // it is done; the chunks shrink towards the end of the launch so that the last workgroups are short ones
-    uint32_t zpb = (uint32_t)tuning("STAGE2_ZPB", 50);
-    const uint32_t ztail = (uint32_t)tuning("STAGE2_ZTAIL", 10);  // 0: chunks of one size
+    // z chunks.  Tile-major order (the default, STAGE2_ORDER 1): the chunks of a tile are consecutive workgroups of one XCD, so
+    // they start together and fetch the tile's per-output plan -- 12 bytes per cell, 0.05 GB per chunk of the benchmark
+    // launch -- once from memory instead of once per chunk, and the chip as a whole works on eight neighbouring tile rows;
+    // chunks of one size (about STAGE2_ZPB slices).  Measured on the benchmark plan (profiles/r02_sweep_[n-r].log): bilinear
+    // 2.40 -> 2.32 ms, nearest 2.32 -> 2.21 ms, 25 slices 0.322 -> 0.303 ms.
+    // Chunk-major order (STAGE2_ORDER 0, round 1 and early round 2): all tiles of chunk 0, then chunk 1, ...; the chunks shrink
+    // towards the end of the launch so that the last workgroups are short ones (STAGE2_ZTAIL).
+    const bool tileMajor = tuning("STAGE2_ORDER", 1) == 1;
+    uint32_t zpb = (uint32_t)tuning("STAGE2_ZPB", tileMajor ? 25 : 50);
+    const uint32_t ztail = tileMajor ? 0u : (uint32_t)tuning("STAGE2_ZTAIL", 10);  // 0: chunks of one size
     if (zpb < 1) zpb = 1;
-    if (ceil_div(nz, (size_t)zpb) > (size_t)kMaxZChunks - 6) zpb = (uint32_t)ceil_div(nz, (size_t)kMaxZChunks - 6);
+    const size_t mostChunks = tileMajor ? 16 : (size_t)kMaxZChunks - 6;
+    if (ceil_div(nz, (size_t)zpb) > mostChunks) zpb = (uint32_t)ceil_div(nz, mostChunks);
     uint32_t nChunks = 0;
-    for (uint32_t z = 0; z < nz;) {
+    if (tileMajor) {
+        const uint32_t n = (uint32_t)ceil_div(nz, (size_t)zpb);
+        for (uint32_t c = 0, z = 0; c < n; ++c) {
+            a.zStart[nChunks++] = z;
+            z += (uint32_t)nz / n + (c < (uint32_t)nz % n ? 1u : 0u);
+        }
+    }
+    for (uint32_t z = 0; !tileMajor && z < nz;) {
         const uint32_t rem = (uint32_t)nz - z;
         uint32_t size = zpb;
         if (ztail > 0 && rem <= 2 * zpb) size = std::max(ztail, (rem + 1) / 2);
@@ -696,7 +718,8 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.zStart[nChunks] = (uint32_t)nz;
     a.slotChunks = slot_chunks(s.ldsBytes, s.depth);
     a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0);
-    const dim3 grid(s.gridX, nChunks, 1);
+    a.nZChunks = tileMajor ? nChunks : 0u;
+    const dim3 grid(tileMajor ? s.gridX * nChunks : s.gridX, tileMajor ? 1u : nChunks, 1);
     switch (plan.kind) {
     case PlanKind::Nearest: launch_shape<1>(s, a, grid, stream); break;
     case PlanKind::Bilinear: launch_shape<2>(s, a, grid, stream); break;

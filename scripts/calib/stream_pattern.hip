@@ -11,6 +11,7 @@
 //   sum3: out = a + b + c with 16-byte global loads and stores: the 3:1 read/write stream at its simplest (ceiling).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,6 +50,14 @@ struct Args {
     uint32_t tw, th;      // outputs per tile
     uint32_t tilesX, nTiles;
     uint32_t flags;
+    // flags & 2048: the footprint of a tile whose target is TILTED against the source rows (the benchmark's rotated pole: ~0.08
+    // source rows per output column): a parallelogram of more, shorter row segments.  rel[c] = (row << 20 | first cell) of chunk c
+    // relative to the tile's corner, the tile to the right continues shearRows further down.
+    const uint32_t* rel;
+    uint32_t relCount, shearRows;
+    // flags & 4096: every workgroup loads a per-output plan entry (4 + 8 bytes) like the product kernel does per (tile, z chunk)
+    const uint32_t* planL;  // zeros
+    const float* planW;
 };
 
 template <int NT, int PER, int UN, int NBUF, bool PRIV>
@@ -72,8 +81,9 @@ __global__ void __launch_bounds__(PRIV ? 256 : NT) tile(Args a)
     if (tile >= a.nTiles) return;
     const uint32_t tx = tile % a.tilesX, ty = tile / a.tilesX;
     const uint32_t nrows = a.th * 3 / 2 + 1, cpr = a.tw / 2 + 1;
-    const uint32_t total = nrows * cpr;
-    const uint32_t r0 = ty * (a.th * 3 / 2), c0 = tx * a.tw * 2;
+    const bool sheared = (a.flags & 2048) != 0;
+    const uint32_t total = sheared ? a.relCount : nrows * cpr;
+    const uint32_t r0 = ty * (a.th * 3 / 2) + (sheared ? tx * a.shearRows : 0u), c0 = tx * a.tw * 2;
 
     uint32_t gOff[UN];
 #pragma unroll
@@ -81,7 +91,8 @@ __global__ void __launch_bounds__(PRIV ? 256 : NT) tile(Args a)
         const uint32_t c = tid + j * NT;
         gOff[j] = 0xFFFFFFFFu;
         if (c < total) {
-            if (a.flags & 4) gOff[j] = (tile * total + c) * 16u;
+            if (sheared) { const uint32_t q = a.rel[c]; gOff[j] = (((r0 + (q >> 20)) % IY) * IX + c0 + (q & 0xFFFFFu)) * 4u; }
+            else if (a.flags & 4) gOff[j] = (tile * total + c) * 16u;
             else gOff[j] = ((r0 + c / cpr) * IX + c0 + (c % cpr) * 4u) * 4u;
         }
     }
@@ -99,6 +110,12 @@ __global__ void __launch_bounds__(PRIV ? 256 : NT) tile(Args a)
         ldsOff[k] = ((ly * 3 / 2) * cpr * 4 + 2 * lx) * 4u;  // bytes
         w0[k] = 0.25f + 0.001f * (float)lx;
         w1[k] = 0.25f + 0.002f * (float)ly;
+        if ((a.flags & 4096) && x < OX && y < OY) {
+            const uint32_t cell = y * OX + x;
+            ldsOff[k] += a.planL[cell];
+            w0[k] = a.planW[cell];
+            w1[k] = a.planW[OX * OY + cell];
+        }
     }
     const uint32_t z0 = blockIdx.y * a.zpb, z1 = min(a.nz, z0 + a.zpb);
     const uint32_t inBytes = IX * IY * 4u, outBytes = OX * OY * 4u;
@@ -406,10 +423,14 @@ static void run(const char* name, double readBytes, double writeBytes, F&& launc
     fflush(stdout);
 }
 
+static uint32_t* gPlanL = nullptr;
+static float* gPlanW = nullptr;
+
 template <int NT, int PER, int UN, int NBUF, bool PRIV>
 static void run_tile(const char* tag, const float* in, float* out, uint32_t nz, uint32_t tw, uint32_t zpb, uint32_t flags)
 {
     Args a{};
+    a.planL = gPlanL; a.planW = gPlanW;
     a.in = in; a.out = out; a.nz = nz; a.zpb = zpb; a.tw = tw; a.th = NT * PER / tw; a.flags = flags;
     a.tilesX = (OX + tw - 1) / tw;
     a.nTiles = a.tilesX * ((OY + a.th - 1) / a.th);
@@ -429,6 +450,48 @@ static void run_tile(const char* tag, const float* in, float* out, uint32_t nz, 
     const double rd = (flags & 1) ? 0 : (double)a.nTiles * nrows * cpr * 16.0 * nz;
     const double wr = (flags & 2) ? 0 : (double)OX * OY * 4.0 * nz;
     run(name, rd, wr, [&] { kern<<<grid, PRIV ? 256 : NT, lds>>>(a); });
+}
+
+// the same launch on a sheared footprint: tau source rows per output column
+template <int NT, int PER, int UN, int NBUF>
+static void run_shear(const float* in, float* out, uint32_t nz, uint32_t tw, uint32_t zpb, uint32_t flags, double tau)
+{
+    Args a{};
+    a.in = in; a.out = out; a.nz = nz; a.zpb = zpb; a.tw = tw; a.th = NT * PER / tw; a.flags = flags | 2048u;
+    a.planL = gPlanL; a.planW = gPlanW;
+    a.tilesX = (OX + tw - 1) / tw;
+    a.nTiles = a.tilesX * ((OY + a.th - 1) / a.th);
+    const int nrows = (int)a.th * 3 / 2 + 1;
+    const int S = (int)(tw * tau + 0.5);
+    std::vector<uint32_t> rel;
+    int rowsUsed = 0;
+    for (int i = 0; i < nrows + S; ++i) {
+        int xlo = 0, xhi = (int)tw - 1;
+        if (tau > 0) {
+            xlo = std::max(0, (int)std::floor((i - nrows) / tau) + 1);
+            xhi = std::min((int)tw - 1, (int)std::floor(i / tau));
+        } else if (i >= nrows) break;
+        if (xhi < xlo) continue;
+        const int first = (2 * xlo) & ~3, last = 2 * xhi + 1;
+        for (int c = first; c <= last; c += 4) rel.push_back(((uint32_t)i << 20) | (uint32_t)c);
+        ++rowsUsed;
+    }
+    if (rel.size() > (size_t)UN * NT) { printf("skip shear %.3f: %zu chunks > %d\n", tau, rel.size(), UN * NT); return; }
+    uint32_t* dRel;
+    CK(hipMalloc(&dRel, rel.size() * 4));
+    CK(hipMemcpy(dRel, rel.data(), rel.size() * 4, hipMemcpyHostToDevice));
+    a.rel = dRel; a.relCount = (uint32_t)rel.size(); a.shearRows = (uint32_t)S;
+    const size_t lds = (size_t)NBUF * UN * NT * 16;
+    auto kern = tile<NT, PER, UN, NBUF, false>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t gx = a.nTiles;
+    if (flags & 32) gx = ((gx + 7) / 8) * 8;
+    const dim3 grid(gx, (nz + zpb - 1) / zpb);
+    char name[256];
+    snprintf(name, sizeof name, "shear tau%.3f rows%d seg%.0fB NT%d PER%d UN%d NBUF%d tw%u th%u zpb%u flags%u", tau, rowsUsed, rel.size() * 16.0 / rowsUsed, NT, PER, UN,
+             NBUF, tw, a.th, zpb, flags);
+    run(name, (double)a.nTiles * rel.size() * 16.0 * nz, (double)OX * OY * 4.0 * nz, [&] { kern<<<grid, NT, lds>>>(a); });
+    CK(hipFree(dRel));
 }
 
 template <int NT, int PER, int UN, int NBUF, int LOADERS>
@@ -508,6 +571,11 @@ int main(int argc, char** argv)
     CK(hipMalloc(&out, nOut * 4));
     fill_kernel<<<4096, 256>>>(in, nIn);
     CK(hipMemset(out, 0, nOut * 4));
+    CK(hipDeviceSynchronize());
+    CK(hipMalloc(&gPlanL, (size_t)OX * OY * 4));
+    CK(hipMalloc(&gPlanW, (size_t)OX * OY * 8));
+    CK(hipMemset(gPlanL, 0, (size_t)OX * OY * 4));
+    fill_kernel<<<1024, 256>>>(gPlanW, (size_t)OX * OY * 2);
     CK(hipDeviceSynchronize());
     auto want = [&](const char* g) { return only[0] == 0 || strstr(only, g) != nullptr; };
 
@@ -632,6 +700,20 @@ int main(int argc, char** argv)
         run_sb<1024, 4, 4, 2, 12>(in, out, nz, 512, 48);
     }
 
+    if (want("shear")) {
+        for (uint32_t flags : {0u, 32u})
+            for (double tau : {0.0, 0.02, 0.04, 0.08, 0.12, 0.2}) {
+                run_shear<1024, 4, 4, 2>(in, out, nz, 512, 50, flags, tau);
+                run_shear<1024, 4, 4, 2>(in, out, nz, 256, 50, flags, tau);
+                run_shear<512, 4, 4, 3>(in, out, nz, 256, 50, flags, tau);
+            }
+    }
+    if (want("plan")) {
+        for (uint32_t zpb : {50u, 25u, 100u, 200u, 10u})
+            for (uint32_t flags : {0u, 4096u})
+                run_tile<1024, 4, 4, 2, false>("plan", in, out, nz, 512, zpb, flags);
+        for (uint32_t flags : {0u, 4096u}) run_shear<1024, 4, 4, 2>(in, out, nz, 512, 50, flags, 0.08);
+    }
     if (want("alu")) {
         for (uint32_t flags : {0u, 512u, 1024u, 1536u, 3u, 512u + 3u, 1024u + 3u, 1536u + 3u}) {
             run_tile<1024, 4, 4, 2, false>("alu", in, out, nz, 512, 50, flags);

@@ -630,9 +630,12 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     if (plan.outX * plan.outY == 0) return false;
     // the float form of the bicubic stencil is as light as the bilinear one: it takes the bilinear shapes
     const bool cubic = plan.kind == PlanKind::Bicubic && !plan.bicubicFast;
-    // measured on the benchmark plan (profiles/r02_sweep_*.log): 1024 threads on 512 x 8 tiles for the 1 x 1 and 2 x 2 stencils
-    // (one workgroup per CU); the 4 x 4 stencil in the reference's arithmetic is FP64-bound and prefers 128 x 8 tiles on 512
-    // threads, in float arithmetic 256 x 8 tiles on 512 threads (its halo makes taller or wider tiles stage more)
+    // measured on the benchmark plan (profiles/r02_sweep_[c-x]*.log): 1024 threads on 512 x 8 tiles (one workgroup per CU) for the
+    // 1 x 1 and 2 x 2 stencils.  With the tile-major launch order 512 threads on 256 x 8 tiles (two workgroups per CU) run the
+    // bilinear launch 2.5-3.5 % faster on two boxes (2.19 against 2.27 ms) and 4 % slower on two others (2.41 against 2.31 ms), and
+    // lose on the 1 x 1 stencil and on short batches everywhere: the shape that behaves the same on every box is kept.  The 4 x 4
+    // stencil in float arithmetic takes 256 x 8 tiles on 512 threads (its halo makes taller or wider tiles stage more), in the
+    // reference's arithmetic it is FP64-bound and prefers 128 x 8 tiles on 512 threads.
     const int nt = tuning("STAGE2_NT", (cubic || plan.bicubicFast) ? 512 : 1024);
     if (!(nt == 256 || nt == 512 || nt == 1024)) return false;
     Shape2 sh{};

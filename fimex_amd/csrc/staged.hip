@@ -158,6 +158,7 @@ struct StagedArgs {
     uint32_t nOut;
     uint32_t nz, zPerBlock;
     uint32_t tilesPerXcd, xcdRemap, storeAux, loadAux;
+    uint32_t nZChunks;  // > 0: flat grid in tile-major order (the z chunks of a tile are consecutive workgroups of one XCD)
     uint32_t ablate;  // tuning build only (FIMEX_AMD_ABLATE): 1 = no source loads, 2 = no output stores
 };
 
@@ -238,7 +239,12 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
     //   xcdRemap 0: tiles in dispatch order (neighbours on different XCDs) -- the default, measured as good as any;
     //   xcdRemap 1: each XCD owns one contiguous band of tile rows;
     //   xcdRemap >= 2: tile rows dealt to the XCDs in stripes of (xcdRemap - 1) rows.
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x, zc = blockIdx.y;
+    if (a.nZChunks != 0) {  // workgroup s runs on XCD s % 8; the k-th workgroup of an XCD is z chunk k % n of the XCD's tile k / n
+        const uint32_t k = blockIdx.x / kXcds;
+        zc = k % a.nZChunks;
+        b = (k / a.nZChunks) * kXcds + blockIdx.x % kXcds;
+    }
     uint32_t tile = b;
     if (a.xcdRemap == 1) {
         tile = (b % kXcds) * a.tilesPerXcd + b / kXcds;
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(kBlock) staged_apply(StagedArgs a)
         tile = ((idx / stripe) * kXcds + b % kXcds) * stripe + idx % stripe;
     }
     if (tile >= a.g.nTiles) return;
-    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z0 = zc * a.zPerBlock;
     const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
     const uint2 hdr = a.tileHdr[tile];
     const uint32_t nr = hdr.x, totalChunks = hdr.y;
@@ -605,11 +611,14 @@ void launch_staged_t(const fimex_amd_regrid_plan& plan, StagedArgs& a, size_t nz
     a.inLayer = plan.inX * plan.inY;
     a.nOut = (uint32_t)(plan.outX * plan.outY);
     a.nz = (uint32_t)nz;
-    uint32_t zpb = (uint32_t)tuning("STAGE_ZPB", 50);
+    // STAGE_ORDER 1: tile-major launch order as in staged2.hip (the z chunks of a tile start together on one XCD, tile rows dealt
+    // to the XCDs one by one); 0: all tiles of z chunk 0, then chunk 1, ...
+    const bool tileMajor = tuning("STAGE_ORDER", 0) == 1;
+    uint32_t zpb = (uint32_t)tuning("STAGE_ZPB", tileMajor ? 25 : 50);
     if (zpb < 1) zpb = 1;
     if (zpb > nz) zpb = (uint32_t)nz;
     a.zPerBlock = zpb;
-    a.xcdRemap = (uint32_t)tuning("XCD", 0);
+    a.xcdRemap = (uint32_t)tuning("XCD", tileMajor ? 2 : 0);
     a.ablate = (uint32_t)tuning("ABLATE", 0);
     a.storeAux = (uint32_t)tuning("STORE_AUX", 2);
     a.loadAux = (uint32_t)tuning("LOAD_AUX", 0);
@@ -620,8 +629,9 @@ void launch_staged_t(const fimex_amd_regrid_plan& plan, StagedArgs& a, size_t nz
         gridX = (uint32_t)ceil_div(s.nTiles, (size_t)stripe * kXcds) * stripe * kXcds;
     }
     const size_t chunks = ceil_div(nz, (size_t)zpb);
-    FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
-    const dim3 grid(gridX, (uint32_t)chunks, 1);
+    FA_REQUIRE(chunks <= 65535 && (size_t)gridX * chunks <= 0x7FFFFFFFu, "too many z chunks for one launch");
+    a.nZChunks = tileMajor ? (uint32_t)chunks : 0u;
+    const dim3 grid(tileMajor ? gridX * (uint32_t)chunks : gridX, tileMajor ? 1u : (uint32_t)chunks, 1);
     const uint32_t key = s.per * 100 + s.kmax;
     if (plan.kind == PlanKind::Nearest) {
         switch (key) {

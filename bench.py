@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=5, help="strong scaling: slices per write-back chunk of the overlapped gather")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-slice, copy and gather measurements")
+    ap.add_argument("--no-tune", action="store_true", help="keep the plan's default workgroup shape (skip fimex_amd_regrid_plan_tune_device)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of three output slices")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device rehearses the N > 1 path on a single-GPU box")
@@ -256,6 +257,11 @@ def main():
     d_out = d_full[first:last] if d_full is not None else torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
 
+    # the plan's two workgroup shapes (identical results) timed on this device and this batch, the faster kept: part of the product
+    # (fimex_amd_regrid_plan_tune_device), done once per plan like the plan build and outside the timed steps
+    tuned_shape = None if args.no_tune else plan.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream)
+    info = plan.info()
+
     def step():
         plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream)
 
@@ -300,7 +306,9 @@ def main():
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
-            rec = json.load(open(tf)).get("%s_nz%d" % (args.method, nz))
+            recs = json.load(open(tf))
+            rec = recs.get("%s_nz%d_%dx%d" % (args.method + ("fast" if fast else ""), nz, info.get("tileW"), info.get("tileH"))) or \
+                recs.get("%s_nz%d" % (args.method + ("fast" if fast else ""), nz))
             if isinstance(rec, dict) and rec.get("tile") == [info.get("tileW"), info.get("tileH")]:
                 traffic, traffic_source = rec["bytes"], rec.get("source")
         except Exception:
@@ -318,7 +326,7 @@ def main():
                         % (args.method, args.nz, "split over the GPUs" if strong else "per GPU"),
             "slices_per_gpu": nz, "slices_total": nz_total, "library": "libfimex_amd_tuning.so" if args.tuning_build else "libfimex_amd.so",
             "sharding": "slices over GPUs, plan replicated, no data-path collective",
-            "plan_build_s": t_plan, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
+            "plan_build_s": t_plan, "tuned_shape": tuned_shape, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
         },
         "verified_slices": verified, "verified_how": "1e-5 of the slice's largest magnitude (FIMEX_AMD_BICUBIC_FAST)" if fast else "bit for bit against the CPU oracle",
         "roofline": {

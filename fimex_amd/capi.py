@@ -65,6 +65,7 @@ SYMBOLS = {
     "fimex_amd_regrid_plan_info": (ctypes.c_int, [_V, ctypes.POINTER(PlanInfo)]),
     "fimex_amd_regrid_apply_host": (ctypes.c_int, [_V, _F, _Z, _F, _Z, _ZP]),
     "fimex_amd_regrid_apply_device": (ctypes.c_int, [_V, _V, _Z, _V, _V]),
+    "fimex_amd_regrid_plan_tune_device": (ctypes.c_int, [_V, _V, _Z, _V, _V, ctypes.POINTER(ctypes.c_int)]),
     "fimex_amd_regrid_slice_host": (ctypes.c_int, [_V, _F, _Z, ctypes.c_float, ctypes.POINTER(Process2d), _Z, _F, ctypes.c_float,
                                                    _V, ctypes.c_int, ctypes.POINTER(Process2d), _Z, _F, _Z, _ZP]),
     "fimex_amd_vector_plan_create": (ctypes.c_int, [_D, _Z, _Z, ctypes.POINTER(_V)]),
@@ -246,6 +247,12 @@ class RegridPlan:
 
     def apply_device(self, d_in, nz, d_out, stream=0):
         _check(load().fimex_amd_regrid_apply_device(self._h, d_in, nz, d_out, stream))
+
+    def tune_device(self, d_in, nz, d_out, stream=0):
+        """Times the plan's workgroup shapes on these device buffers and keeps the faster (0: default shape, 1: the other)."""
+        chosen = ctypes.c_int(0)
+        _check(load().fimex_amd_regrid_plan_tune_device(self._h, d_in, nz, d_out, stream, ctypes.byref(chosen)))
+        return chosen.value
 
 
 class VectorPlan:

@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <algorithm>
+#include <vector>
 
 namespace fimex_amd {
 
@@ -272,6 +274,53 @@ int fimex_amd_regrid_apply_device(const fimex_amd_regrid_plan* plan, const float
         FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
         require_current_device(plan->device);
         apply_device(*plan, d_in, nz, d_out, as_stream(stream));
+    });
+}
+
+int fimex_amd_regrid_plan_tune_device(fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream, int* chosenShape)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        if (chosenShape) *chosenShape = plan->useAlt;
+        if (nz == 0 || !plan->staged2Alt.valid || !plan->staged2.valid) return;
+        FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
+        require_current_device(plan->device);
+        hipStream_t st = as_stream(stream);
+        hipEvent_t e0, e1;
+        FA_HIP(hipEventCreate(&e0));
+        FA_HIP(hipEventCreate(&e1));
+        float best[2] = {0.f, 0.f};
+        try {
+            for (int shape = 0; shape < 2; ++shape) {
+                plan->useAlt = shape;
+                std::vector<float> ms;
+                for (int rep = 0; rep < 7; ++rep) {  // two launches to settle, five timed: the median counts
+                    FA_HIP(hipEventRecord(e0, st));
+                    apply_device(*plan, d_in, nz, d_out, st);
+                    FA_HIP(hipEventRecord(e1, st));
+                    FA_HIP(hipEventSynchronize(e1));
+                    float t = 0.f;
+                    FA_HIP(hipEventElapsedTime(&t, e0, e1));
+                    if (rep >= 2) ms.push_back(t);
+                }
+                std::sort(ms.begin(), ms.end());
+                best[shape] = ms[ms.size() / 2];
+            }
+        } catch (...) {
+            plan->useAlt = 0;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            throw;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        plan->useAlt = best[1] < 0.99f * best[0] ? 1 : 0;  // the default shape unless the other one is clearly faster
+        const auto& s = plan->useAlt ? plan->staged2Alt : plan->staged2;
+        plan->info.planBytes = plan->planBytesShape[plan->useAlt];
+        plan->info.stagedCells = s.stagedCells;
+        plan->info.tileW = s.tileWMax;
+        plan->info.tileH = s.tileH;
+        if (chosenShape) *chosenShape = plan->useAlt;
     });
 }
 

@@ -593,7 +593,12 @@ void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const 
         const auto& s = plan.staged2;
         const size_t perCell = plan.kind == PlanKind::Nearest ? 0 : (plan.kind == PlanKind::Bilinear ? plan.xf.bytes() + plan.yf.bytes()
                                                                                                        : plan.xfd.bytes() + plan.yfd.bytes());
-        plan.info.planBytes = perCell + s.ldsA.bytes() + s.ldsB.bytes() + s.totalChunks * 4 + (size_t)s.nTiles * sizeof(StagedTile) + s.order.bytes();
+        auto bytes_of = [&](const Staged2Plan& q) {
+            return perCell + q.ldsA.bytes() + q.ldsB.bytes() + q.totalChunks * 4 + (size_t)q.nTiles * sizeof(StagedTile) + q.order.bytes();
+        };
+        plan.planBytesShape[0] = bytes_of(s);
+        plan.planBytesShape[1] = plan.staged2Alt.valid ? bytes_of(plan.staged2Alt) : 0;
+        plan.info.planBytes = plan.planBytesShape[0];
         plan.info.stagedCells = s.stagedCells;
         plan.info.tileW = s.tileWMax;
         plan.info.tileH = s.tileH;

@@ -484,7 +484,7 @@ void launch_shape(const Staged2Plan& s, const Staged2Args& a, dim3 grid, hipStre
 }
 
 template <int STENCIL>
-bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream, const Shape2& sh, uint32_t stripe)
+bool build_shape(fimex_amd_regrid_plan& plan, Staged2Plan& s, const double* d_px, const double* d_py, hipStream_t stream, const Shape2& sh, uint32_t stripe)
 {
     const uint32_t outX = (uint32_t)plan.outX, outY = (uint32_t)plan.outY;
     const uint32_t tileH = sh.tileH;
@@ -582,7 +582,6 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
     if (total > 0xFFFFFFFFull) return false;
     FA_HIP(hipMemcpyAsync(dTiles.get(), tiles.data(), tiles.size() * sizeof(StagedTile), hipMemcpyHostToDevice, stream));
     const size_t n = plan.outX * plan.outY;
-    Staged2Plan& s = plan.staged2;
     s.chunkOff.allocate(std::max<size_t>(total, 1));
     s.ldsA.allocate(n);
     s.ldsB.allocate(STENCIL == 4 ? n : 0);
@@ -625,7 +624,8 @@ bool build_shape(fimex_amd_regrid_plan& plan, const double* d_px, const double* 
 
 // Workgroup shape by stencil (tuning: STAGE2_NT / STAGE2_TW / STAGE2_LDS / STAGE2_STRIPE); false: no staged form for this
 // plan (positions without spatial coherence), the caller keeps the gather kernels.
-bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+namespace {
+bool build_staged2_shape(fimex_amd_regrid_plan& plan, Staged2Plan& target, int ntWanted, const double* d_px, const double* d_py, hipStream_t stream)
 {
     if (plan.outX * plan.outY == 0) return false;
     // the float form of the bicubic stencil is as light as the bilinear one: it takes the bilinear shapes
@@ -636,7 +636,7 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     // lose on the 1 x 1 stencil and on short batches everywhere: the shape that behaves the same on every box is kept.  The 4 x 4
     // stencil in float arithmetic takes 256 x 8 tiles on 512 threads (its halo makes taller or wider tiles stage more), in the
     // reference's arithmetic it is FP64-bound and prefers 128 x 8 tiles on 512 threads.
-    const int nt = tuning("STAGE2_NT", (cubic || plan.bicubicFast) ? 512 : 1024);
+    const int nt = ntWanted > 0 ? ntWanted : tuning("STAGE2_NT", (cubic || plan.bicubicFast) ? 512 : 1024);
     if (!(nt == 256 || nt == 512 || nt == 1024)) return false;
     Shape2 sh{};
     sh.nt = nt;
@@ -658,16 +658,30 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     // the bilinear launch at the same time; with the tile-major order stripes of 2, 4 or 8 rows lose 3-6 %.)
     const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", 1));
     switch (plan.kind) {
-    case PlanKind::Nearest: return build_shape<1>(plan, d_px, d_py, stream, sh, stripe);
-    case PlanKind::Bilinear: return build_shape<2>(plan, d_px, d_py, stream, sh, stripe);
-    case PlanKind::Bicubic: return build_shape<4>(plan, d_px, d_py, stream, sh, stripe);
+    case PlanKind::Nearest: return build_shape<1>(plan, target, d_px, d_py, stream, sh, stripe);
+    case PlanKind::Bilinear: return build_shape<2>(plan, target, d_px, d_py, stream, sh, stripe);
+    case PlanKind::Bicubic: return build_shape<4>(plan, target, d_px, d_py, stream, sh, stripe);
     default: return false;
     }
 }
+}  // namespace
+
+bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream)
+{
+    if (!build_staged2_shape(plan, plan.staged2, 0, d_px, d_py, stream)) return false;
+    // the bilinear plan also holds the 512-thread shape (two workgroups per CU): faster on some devices for long batches,
+    // slower on others and for short ones -- fimex_amd_regrid_plan_tune_device decides on the spot, the default stays
+    if (plan.kind == PlanKind::Bilinear && plan.staged2.nt == 1024 && tuning("STAGE2_ALT", 1) != 0)
+        build_staged2_shape(plan, plan.staged2Alt, 512, d_px, d_py, stream);
+    return true;
+}
+
 
 void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
 {
-    const Staged2Plan& s = plan.staged2;
+    const int forced = tuning("STAGE2_USE_ALT", -1);  // tuning build: 0 / 1 overrides the plan's choice
+    const bool alt = plan.staged2Alt.valid && (forced >= 0 ? forced == 1 : plan.useAlt != 0);
+    const Staged2Plan& s = alt ? plan.staged2Alt : plan.staged2;
     Staged2Args a{};
     a.in = d_in;
     a.out = d_out;

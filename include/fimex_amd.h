@@ -156,6 +156,17 @@ int fimex_amd_regrid_apply_host(const fimex_amd_regrid_plan* plan,
 int fimex_amd_regrid_apply_device(const fimex_amd_regrid_plan* plan,
                                   const float* d_in, size_t nz, float* d_out, void* stream);
 
+/**
+ * Optional, no counterpart in the reference: a bilinear plan holds its LDS-staged form in two workgroup shapes with identical
+ * results, and which of them is faster depends on the device at hand and on the batch length.  This call regrids
+ * the caller's nz slices a few times with each shape (d_out ends up holding the regridded slices), keeps the faster one for every
+ * later apply of this plan and reports it in *chosenShape (0: the default shape, 1: the other; NULL allowed).  Plans without a
+ * second shape and batches too short for the staged kernels return 0 at once.  Synchronises the stream; not to be called while
+ * other threads apply the same plan.
+ */
+int fimex_amd_regrid_plan_tune_device(fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream,
+                                      int* chosenShape);
+
 /* ---------------------------------------------------------- vector rotation */
 /**
  * Opaque rotation plan.  Replaces CachedVectorReprojection

@@ -513,6 +513,48 @@ def test_device_resident_apply_matches_host_apply(fa):
     assert cases.same(d_out.cpu().numpy(), oracle.interpolate_values(oracle.BICUBIC, px, py, f, inX, inY, outX, outY))
 
 
+def test_plan_tune_keeps_results_and_both_shapes_match_the_oracle(fa, monkeypatch, tuning_build):
+    """fimex_amd_regrid_plan_tune_device: a bilinear plan holds two workgroup shapes of its LDS-staged form (1024 threads on
+    512 x 8 tiles, 512 threads on 256 x 8); the call times both on the caller's buffers and keeps one.  Whatever it picks,
+    and with either shape forced (tuning build), the result is the oracle's bit for bit; plans without a second shape
+    (nearest, forward) and empty batches answer 0."""
+    import torch
+    inX, inY, outX, outY, nz = 1441, 721, 900, 500, 9
+    px, py = cases.coherent_positions(inX, inY, outX, outY, seed=41, outliers=4)
+    f = cases.field(nz, inY, inX, seed=42)
+    want = oracle.interpolate_values(oracle.BILINEAR, px, py, f, inX, inY, outX, outY)
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.from_numpy(f).cuda()
+    d_out = torch.full((nz, outY, outX), 7.0, device="cuda")
+    plan = fa.RegridPlan(oracle.BILINEAR, px, py, inX, inY, outX, outY)
+    before = plan.info()
+    assert before["stagedCells"] > 0 and before["tileW"] == 512
+    chosen = plan.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), st)
+    assert chosen in (0, 1)
+    assert cases.same(d_out.cpu().numpy(), want)  # the tuning launches leave the regridded slices behind
+    after = plan.info()
+    assert after["tileW"] == (256 if chosen else 512) and after["stagedCells"] > 0 and after["planBytes"] > 0
+    d_out.fill_(7.0)
+    plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert cases.same(d_out.cpu().numpy(), want)
+    assert cases.same(plan.apply_host(f), want)
+    for forced in ("0", "1"):
+        monkeypatch.setenv("FIMEX_AMD_STAGE2_USE_ALT", forced)
+        d_out.fill_(7.0)
+        plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert cases.same(d_out.cpu().numpy(), want), "shape %s: %s" % (forced, cases.describe_mismatch(d_out.cpu().numpy(), want))
+    monkeypatch.delenv("FIMEX_AMD_STAGE2_USE_ALT")
+    assert plan.tune_device(d_in.data_ptr(), 0, d_out.data_ptr(), st) == chosen  # nothing to time: the choice stands
+    near = fa.RegridPlan(oracle.NEAREST, px, py, inX, inY, outX, outY)
+    assert near.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), st) == 0
+    assert cases.same(near.apply_host(f), oracle.interpolate_values(oracle.NEAREST, px, py, f, inX, inY, outX, outY))
+    fpx, fpy = cases.forward_positions(inX, inY, outX, outY, seed=43)
+    fwd = fa.RegridPlan(oracle.FWD_MEAN, fpx, fpy, inX, inY, outX, outY)
+    assert fwd.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), st) == 0
+
+
 def test_concurrent_host_applies_are_reentrant(fa):
     """interpolateValues is called from concurrent OpenMP tasks in the reference's writers
     (src/NetCDF_CDMWriter.cc:749-753): several threads, one plan."""

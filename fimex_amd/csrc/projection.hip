@@ -11,7 +11,8 @@
 // (Snyder eq. 7-7, 7-9, 15-7..15-11, 21-33..21-40, 8-9..8-25, 3-21).  Geodetic coordinates pass unchanged between the
 // two sides unless both name a datum (+datum, +towgs84) and the two differ: then pj_datum_transform's three- or
 // seven-parameter shift is applied at height 0.  Everything else not implemented is refused (+units, +to_meter, +pm,
-// +axis, +geoc, +over, grid shifts).
+// +geoc, +over, grid shifts).  +units / +to_meter scale the projected coordinates as pj_fwd / pj_inv do, +pm shifts
+// longitudes as pj_transform does.
 #include "plan.hpp"
 
 #include <cmath>
@@ -48,6 +49,8 @@ struct ProjParams {
     double pn1, pp, rp, pfact;    // nsper (sinph0 / cosph0 and the aspect in mode as for stere; sinu: en; cea: k0, qp, apa)
     double oA, oB, oE, ArB, BrA, rB, singam, cosgam, sinrot, cosrot, v_pole_n, v_pole_s, u_0;  // omerc (no_rot in mode)
     double towgs84[7];            // pj_datum_set: dx dy dz (m), rx ry rz (rad), scale factor
+    double toMeter, frMeter;      // pj_init: +units / +to_meter (1 for metres); pj_fwd multiplies by fr_meter, pj_inv by to_meter
+    double fromGreenwich;         // pj_init: +pm, radians east of Greenwich
     int datumType, doShift;       // 0 unknown, 1 three parameters, 2 seven, 3 WGS84; doShift: set on both sides of a pair that needs pj_datum_transform
 };
 
@@ -235,11 +238,51 @@ ProjParams parse_proj4(const char* text)
     auto rad = [&](const char* k, double d) { return has(k) ? num(k, 0) * kPi / 180.0 : d; };
     if (!has("proj")) throw Error("projection string without +proj: " + proj4);
     const std::string name = par["proj"];
-    for (const char* k : {"geoc", "over", "pm", "axis", "to_meter", "vto_meter", "nadgrids", "geoidgrids", "R_A", "R_V", "R_a", "R_g", "R_h",
-                          "R_lat_a", "R_lat_g"})
+    for (const char* k : {"geoc", "over", "vto_meter", "nadgrids", "geoidgrids", "R_A", "R_V", "R_a", "R_g", "R_h", "R_lat_a", "R_lat_g"})
         if (has(k)) throw Error("projection parameter +" + std::string(k) + " is not implemented: " + proj4);
-    if (has("units") && par["units"] != "m") throw Error("projection +units other than m are not implemented: " + proj4);
+    if (has("axis") && par["axis"] != "enu") throw Error("projection +axis other than enu is not implemented: " + proj4);
     ProjParams p{};
+    // pj_init: +to_meter=<number>[/<number>] wins over +units=<name> (pj_units.c)
+    p.toMeter = 1;
+    if (has("to_meter") || has("units")) {
+        std::string v;
+        if (has("to_meter")) v = par["to_meter"];
+        else {
+            static const struct { const char* id; const char* toMeter; } kUnits[] = {
+                {"km", "1000."}, {"m", "1."}, {"dm", "1/10"}, {"cm", "1/100"}, {"mm", "1/1000"}, {"kmi", "1852.0"}, {"in", "0.0254"},
+                {"ft", "0.3048"}, {"yd", "0.9144"}, {"mi", "1609.344"}, {"fath", "1.8288"}, {"ch", "20.1168"}, {"link", "0.201168"},
+                {"us-in", "1./39.37"}, {"us-ft", "0.304800609601219"}, {"us-yd", "0.914401828803658"}, {"us-ch", "20.11684023368047"},
+                {"us-mi", "1609.347218694437"}, {"ind-yd", "0.91439523"}, {"ind-ft", "0.30479841"}, {"ind-ch", "20.11669506"}};
+            for (const auto& u : kUnits)
+                if (par["units"] == u.id) v = u.toMeter;
+            if (v.empty()) throw Error("unknown +units: " + proj4);
+        }
+        try {
+            size_t used = 0;
+            p.toMeter = std::stod(v, &used);
+            if (used < v.size() && v[used] == '/') p.toMeter /= std::stod(v.substr(used + 1));
+        } catch (...) { throw Error("+to_meter is not a number: " + proj4); }
+        if (!(p.toMeter > 0)) throw Error("invalid +to_meter: " + proj4);
+    }
+    p.frMeter = 1. / p.toMeter;
+    if (has("pm")) {  // pj_init: a name of pj_prime_meridians or an angle (here: decimal degrees, positive east)
+        static const struct { const char* id; double deg; } kMeridians[] = {
+            {"greenwich", 0.}, {"lisbon", -(9 + 7 / 60. + 54.862 / 3600.)}, {"paris", 2 + 20 / 60. + 14.025 / 3600.},
+            {"bogota", -(74 + 4 / 60. + 51.3 / 3600.)}, {"madrid", -(3 + 41 / 60. + 16.58 / 3600.)}, {"rome", 12 + 27 / 60. + 8.4 / 3600.},
+            {"bern", 7 + 26 / 60. + 22.5 / 3600.}, {"jakarta", 106 + 48 / 60. + 27.79 / 3600.}, {"ferro", -(17 + 40 / 60.)},
+            {"brussels", 4 + 22 / 60. + 4.71 / 3600.}, {"stockholm", 18 + 3 / 60. + 29.8 / 3600.}, {"athens", 23 + 42 / 60. + 58.815 / 3600.},
+            {"oslo", 10 + 43 / 60. + 22.5 / 3600.}};
+        bool named = false;
+        for (const auto& m : kMeridians)
+            if (par["pm"] == m.id) { p.fromGreenwich = m.deg * kPi / 180.0; named = true; }
+        if (!named) {
+            size_t used = 0;
+            double deg = 0;
+            try { deg = std::stod(par["pm"], &used); } catch (...) { used = 0; }
+            if (used == 0 || used != par["pm"].size()) throw Error("+pm is neither a known meridian nor decimal degrees: " + proj4);
+            p.fromGreenwich = deg * kPi / 180.0;
+        }
+    }
     // pj_ell_set: an explicit +a wins over the one +ellps implies; the shape is the first of +es +e +rf +f +b
     p.a = 1;
     p.datum = has("datum") || has("towgs84");
@@ -569,6 +612,7 @@ ProjParams parse_proj4(const char* text)
         }
     } else if (name == "ob_tran") {
         p.kind = kObTran;
+        if (p.toMeter != 1) throw Error("+units / +to_meter with ob_tran are not implemented: " + proj4);
         if (p.es != 0) throw Error("ob_tran is implemented on the sphere only: " + proj4);
         if (!has("o_proj") || !geographic_name(par["o_proj"]) || !has("o_lat_p"))
             throw Error("ob_tran is implemented for +o_proj=longlat +o_lat_p only: " + proj4);
@@ -850,8 +894,8 @@ __device__ void proj_forward(const ProjParams& p, double lon, double lat, double
         y = py + p.y0;
         return;
     }
-    x = p.a * px + p.x0;
-    y = p.a * py + p.y0;
+    x = p.frMeter * (p.a * px + p.x0);  // pj_fwd.c
+    y = p.frMeter * (p.a * py + p.y0);
 }
 
 // projected -> geographic (rad)
@@ -860,7 +904,7 @@ __device__ void proj_inverse(const ProjParams& p, double x, double y, double& lo
     if (p.kind == kLatLong) { lon = x; lat = y; return; }
     double xs, ys;
     if (p.kind == kObTran) { xs = x - p.x0; ys = y - p.y0; }
-    else { xs = (x - p.x0) / p.a; ys = (y - p.y0) / p.a; }
+    else { xs = (x * p.toMeter - p.x0) / p.a; ys = (y * p.toMeter - p.y0) / p.a; }  // pj_inv.c
     double lam = 0, phi = 0;
     if (p.kind == kStere && p.es != 0) {  // PJ_stere.c e_inverse
         const double rho = hypot(xs, ys);
@@ -1272,7 +1316,9 @@ __device__ __forceinline__ void transform_point(const ProjParams& src, const Pro
 {
     double lon, lat;
     proj_inverse(src, x, y, lon, lat);
+    lon += src.fromGreenwich;  // pj_transform.c: longitudes meet relative to Greenwich
     if (src.doShift) datum_shift(src, dst, lon, lat);
+    lon -= dst.fromGreenwich;
     proj_forward(dst, lon, lat, x, y);
 }
 

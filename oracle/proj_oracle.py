@@ -75,8 +75,46 @@ ELLIPSOIDS = {
 DATUMS = {"WGS84": "WGS84", "NAD83": "GRS80", "GGRS87": "GRS80", "potsdam": "bessel"}  # pj_datums.c entries without a grid
 DATUM_SHIFTS = {"WGS84": "0,0,0", "NAD83": "0,0,0", "GGRS87": "-199.87,74.79,246.62", "potsdam": "598.1,73.7,418.2,0.202,0.045,-2.455,6.7"}
 _SEC_TO_RAD = 4.84813681109535993589914102357e-6
-_UNSUPPORTED = ("geoc", "over", "pm", "axis", "to_meter", "vto_meter", "nadgrids", "geoidgrids",
+_UNSUPPORTED = ("geoc", "over", "vto_meter", "nadgrids", "geoidgrids",
                 "R_A", "R_V", "R_a", "R_g", "R_h", "R_lat_a", "R_lat_g")
+
+# pj_units.c: +units=<id> -> to_meter (text as PROJ.4 stores it: a number or a quotient)
+UNITS = {"km": "1000.", "m": "1.", "dm": "1/10", "cm": "1/100", "mm": "1/1000", "kmi": "1852.0", "in": "0.0254", "ft": "0.3048",
+         "yd": "0.9144", "mi": "1609.344", "fath": "1.8288", "ch": "20.1168", "link": "0.201168", "us-in": "1./39.37",
+         "us-ft": "0.304800609601219", "us-yd": "0.914401828803658", "us-ch": "20.11684023368047", "us-mi": "1609.347218694437",
+         "ind-yd": "0.91439523", "ind-ft": "0.30479841", "ind-ch": "20.11669506"}
+# pj_datums.c pj_prime_meridians, degrees east of Greenwich
+PRIME_MERIDIANS = {"greenwich": 0., "lisbon": -(9 + 7 / 60. + 54.862 / 3600.), "paris": 2 + 20 / 60. + 14.025 / 3600.,
+                   "bogota": -(74 + 4 / 60. + 51.3 / 3600.), "madrid": -(3 + 41 / 60. + 16.58 / 3600.), "rome": 12 + 27 / 60. + 8.4 / 3600.,
+                   "bern": 7 + 26 / 60. + 22.5 / 3600., "jakarta": 106 + 48 / 60. + 27.79 / 3600., "ferro": -(17 + 40 / 60.),
+                   "brussels": 4 + 22 / 60. + 4.71 / 3600., "stockholm": 18 + 3 / 60. + 29.8 / 3600., "athens": 23 + 42 / 60. + 58.815 / 3600.,
+                   "oslo": 10 + 43 / 60. + 22.5 / 3600.}
+
+
+def to_meter_of(p):
+    """pj_init: +to_meter=<number>[/<number>] wins over +units=<id>; 1 without either."""
+    if "to_meter" in p:
+        text = p["to_meter"]
+    elif "units" in p:
+        if p["units"] not in UNITS:
+            raise NotImplementedError("+units=%s" % p["units"])
+        text = UNITS[p["units"]]
+    else:
+        return 1.0
+    num, _, den = text.partition("/")
+    v = float(num)
+    if den:
+        v /= float(den)
+    if not v > 0:
+        raise ValueError("invalid +to_meter: %r" % (p,))
+    return v
+
+
+def from_greenwich_of(p):
+    """pj_init: +pm=<name of pj_prime_meridians | decimal degrees east>, in radians."""
+    if "pm" not in p:
+        return 0.0
+    return math.radians(PRIME_MERIDIANS[p["pm"]] if p["pm"] in PRIME_MERIDIANS else float(p["pm"]))
 
 
 def _ellipsoid(p):
@@ -85,8 +123,8 @@ def _ellipsoid(p):
     for k in _UNSUPPORTED:
         if k in p:
             raise NotImplementedError("+%s is not restated: %r" % (k, p))
-    if p.get("units", "m") != "m":
-        raise NotImplementedError("+units other than m: %r" % (p,))
+    if p.get("axis", "enu") != "enu":
+        raise NotImplementedError("+axis other than enu: %r" % (p,))
     if "R" in p:
         return float(p["R"]), 0.0
     q = dict(p)
@@ -280,7 +318,12 @@ class _Proj:
         self.x0 = float(self.p.get("x_0", 0.0))
         self.y0 = float(self.p.get("y_0", 0.0))
         self.k0 = float(self.p.get("k_0", self.p.get("k", 1.0)))
+        self.to_meter = to_meter_of(self.p)
+        self.fr_meter = 1.0 / self.to_meter
+        self.from_greenwich = from_greenwich_of(self.p)
         self.latlong = is_latlong(self.p)
+        if self.name == "ob_tran" and self.to_meter != 1.0:
+            raise NotImplementedError("+units with ob_tran")
         getattr(self, "_setup_" + self._kind())()
 
     def _kind(self):
@@ -1205,7 +1248,7 @@ class _Proj:
         x, y = getattr(self, "_fwd_" + self.name)(lam, lat)
         if self.name == "ob_tran":
             return x + self.x0, y + self.y0
-        return self.a * x + self.x0, self.a * y + self.y0
+        return self.fr_meter * (self.a * x + self.x0), self.fr_meter * (self.a * y + self.y0)  # pj_fwd.c
 
     def inverse(self, x, y):
         x = np.asarray(x, dtype=np.float64)
@@ -1215,7 +1258,7 @@ class _Proj:
         if self.name == "ob_tran":
             xs, ys = x - self.x0, y - self.y0
         else:
-            xs, ys = (x - self.x0) / self.a, (y - self.y0) / self.a
+            xs, ys = (x * self.to_meter - self.x0) / self.a, (y * self.to_meter - self.y0) / self.a  # pj_inv.c
         lam, phi = getattr(self, "_inv_" + self.name)(xs, ys)
         return adjlon(lam + self.lam0), phi
 
@@ -1224,7 +1267,9 @@ def transform(src, dst, x, y):
     """pj_transform(src, dst, ...): coordinates of src -> coordinates of dst (no datum shift)."""
     ps, pd = _Proj(src), _Proj(dst)
     lon, lat = ps.inverse(x, y)
+    lon = lon + ps.from_greenwich  # pj_transform.c: longitudes meet relative to Greenwich
     lon, lat = datum_transform(ps, pd, lon, lat)
+    lon = lon - pd.from_greenwich
     return pd.forward(lon, lat)
 
 

@@ -158,14 +158,40 @@ def test_axes_between_an_ellipsoid_and_a_sphere(fa):
 
 def test_unsupported_projection_strings_fail_loudly(fa):
     for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=0 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84", "+lat_0=3",
-                "+proj=ob_tran +o_proj=stere +R=1", "+proj=ob_tran +o_proj=longlat +o_lat_p=30 +ellps=WGS84", "+proj=merc +ellps=WGS84 +units=km",
+                "+proj=ob_tran +o_proj=stere +R=1", "+proj=ob_tran +o_proj=longlat +o_lat_p=30 +ellps=WGS84", "+proj=merc +ellps=WGS84 +units=parsec", "+proj=merc +R=6371000 +to_meter=0", "+proj=merc +R=6371000 +axis=wsu",
+                "+proj=ob_tran +o_proj=longlat +o_lat_p=30 +R=6371000 +units=km", "+proj=merc +R=6371000 +pm=12d30",
                 "+proj=merc +datum=NAD27", "+proj=merc +ellps=nonesuch", "+proj=stere +lat_0=90", "+proj=lcc +lat_1=30 +lat_2=-30 +R=1",
-                "+proj=merc +R=6371000 +pm=oslo", "+proj=omerc +lat_0=60 +R=6371000", "+proj=ortho +lat_0=40 +ellps=WGS84", "+proj=nsper +lat_0=40 +R=6371000",
+                "+proj=omerc +lat_0=60 +R=6371000", "+proj=ortho +lat_0=40 +ellps=WGS84", "+proj=nsper +lat_0=40 +R=6371000",
                 "+proj=moll +R=6371000"):
         with pytest.raises(fa.FimexAmdError):
             fa.project_values_host(GEO, bad, np.zeros(3), np.zeros(3))
     with pytest.raises(fa.FimexAmdError):  # grid shifts
         fa.project_values_host(GEO_W, "+proj=latlong +ellps=clrk66 +nadgrids=conus", np.zeros(3), np.zeros(3))
+
+
+@pytest.mark.parametrize("proj", [STERE, LCC, UTM33, MERC_W, LAEA_W])
+@pytest.mark.parametrize("extra", ["+units=km", "+units=us-ft", "+to_meter=1/3.2808", "+pm=paris", "+pm=-17.5", "+units=km +pm=oslo", "+axis=enu +units=m"])
+def test_units_and_prime_meridians_on_the_gpu(fa, proj, extra):
+    """+units / +to_meter (pj_fwd.c, pj_inv.c) and +pm (pj_transform.c) on either side of a transformation, against the numpy oracle."""
+    rng = np.random.default_rng(len(proj) + len(extra))
+    lon = np.radians(rng.uniform(2, 28, 5000))
+    lat = np.radians(rng.uniform(45, 80, 5000))
+    geo = GEO_W if "ellps" in proj or "datum" in proj else GEO
+    dst = proj + " " + extra
+    x, y = fa.project_values_host(geo, dst, lon, lat)
+    wx, wy = po.transform(geo, dst, lon, lat)
+    _close(x, wx, dst); _close(y, wy, dst)
+    bx, by = fa.project_values_host(dst, geo, x, y)
+    np.testing.assert_allclose(bx, lon, atol=1e-11); np.testing.assert_allclose(by, lat, atol=1e-11)
+    if "pm" in extra:  # the meridian on the geographic side
+        gx, gy = fa.project_values_host(geo + " +pm=lisbon", proj, lon, lat)
+        vx, vy = po.transform(geo + " +pm=lisbon", proj, lon, lat)
+        _close(gx, vx, proj); _close(gy, vy, proj)
+    ax, ay = np.linspace(2e5, 6e5, 40) / po.to_meter_of(po.parse(dst)), np.linspace(5.5e6, 6.5e6, 30) / po.to_meter_of(po.parse(dst))
+    if proj == UTM33:
+        gx, gy = fa.project_axes_host(dst, geo, ax, ay)
+        vx, vy = po.project_axes(dst, geo, ax, ay)
+        np.testing.assert_allclose(gx.ravel(), vx, atol=1e-12); np.testing.assert_allclose(gy.ravel(), vy, atol=1e-12)
 
 
 def test_datum_shifts_on_the_gpu(fa):

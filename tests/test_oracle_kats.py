@@ -524,8 +524,39 @@ def test_ellipsoid_parameters_follow_pj_ell_set():
     assert P("+proj=merc +a=6378137 +f=0.0033528106647474805").es == pytest.approx(0.0066943799901413165, rel=1e-12)
     assert P("+proj=merc +R=6371000 +ellps=WGS84").es == 0.0                 # +R wins over everything
     for bad in ("+proj=utm +zone=33 +R=6371000", "+proj=utm +zone=61 +ellps=WGS84", "+proj=stere +lat_0=0 +ellps=WGS84",
-                "+proj=merc +ellps=WGS84 +units=km", "+proj=merc +datum=NAD27"):
+                "+proj=merc +ellps=WGS84 +units=parsec", "+proj=merc +datum=NAD27"):
         with pytest.raises((NotImplementedError, ValueError)):
             P(bad)
     with pytest.raises((NotImplementedError, KeyError)):   # grid shifts are not restated
         po.transform("+proj=latlong +datum=WGS84", "+proj=latlong +ellps=clrk66 +nadgrids=conus", np.zeros(1), np.zeros(1))
+
+
+def test_units_and_prime_meridians_follow_pj_fwd_pj_inv_and_pj_transform():
+    """+units / +to_meter scale projected coordinates (pj_fwd.c: fr_meter * (a x + x_0); pj_inv.c: (x to_meter - x_0) / a), +pm shifts
+    longitudes where the two sides meet (pj_transform.c).  Known answers: the US survey foot is 1200/3937 m and the Paris
+    meridian lies 2.5969213 grads east of Greenwich (EPSG 8903); PROJ.4 is not in the reference tree: **parity unpinned** beyond these."""
+    assert po.to_meter_of(po.parse("+proj=merc +units=us-ft")) == pytest.approx(1200.0 / 3937.0, rel=1e-15)
+    assert po.to_meter_of(po.parse("+proj=merc +units=us-in")) == pytest.approx(100.0 / 3937.0, rel=1e-15)
+    assert po.to_meter_of(po.parse("+proj=merc +units=km +to_meter=1/3.2808")) == pytest.approx(1 / 3.2808, rel=1e-15)  # +to_meter wins
+    assert math.degrees(po.from_greenwich_of(po.parse("+proj=merc +pm=paris"))) == pytest.approx(2.5969213 * 0.9, abs=2e-8)
+    assert math.degrees(po.from_greenwich_of(po.parse("+proj=merc +pm=ferro"))) == pytest.approx(-(17 + 40 / 60.0), abs=1e-12)
+    stere = "+proj=stere +lat_0=90 +lon_0=10 +lat_ts=60 +R=6371000 +x_0=1000 +y_0=-500"
+    geo = "+proj=latlong +R=6371000"
+    rng = np.random.default_rng(3)
+    lon, lat = np.radians(rng.uniform(-40, 60, 500)), np.radians(rng.uniform(40, 89, 500))
+    x, y = po.transform(geo, stere, lon, lat)
+    for unit, f in (("km", 1000.0), ("ft", 0.3048), ("us-ft", 1200.0 / 3937.0)):
+        xk, yk = po.transform(geo, stere + " +units=" + unit, lon, lat)
+        np.testing.assert_allclose(xk * f, x, rtol=1e-15, atol=1e-9)
+        np.testing.assert_allclose(yk * f, y, rtol=1e-15, atol=1e-9)
+        bl, bt = po.transform(stere + " +units=" + unit, geo, xk, yk)
+        np.testing.assert_allclose(bl, lon, atol=1e-12); np.testing.assert_allclose(bt, lat, atol=1e-12)
+    # a grid referred to Paris: its longitudes are smaller by the meridian's offset, the same point on the ground
+    xp, yp = po.transform(geo + " +pm=paris", stere, lon - po.from_greenwich_of({"pm": "paris"}), lat)
+    np.testing.assert_allclose(xp, x, atol=1e-6); np.testing.assert_allclose(yp, y, atol=1e-6)
+    lo, la = po.transform(stere, geo + " +pm=-17.5", x, y)
+    np.testing.assert_allclose(lo, lon + math.radians(17.5), atol=1e-12); np.testing.assert_allclose(la, lat, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        po.transform(geo, stere + " +units=parsec", lon, lat)
+    with pytest.raises(NotImplementedError):
+        po.transform(geo, stere + " +axis=wsu", lon, lat)

@@ -385,7 +385,14 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                         r = pick(mNnx[k], pick(mNny[k], s00[k], liny), pick(mNny[k], top, inter));
                         r = pick(mUndef[k], undefined_f(), r);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+                    // result stores: non-temporal and written through (sc1 nt): 0.4-1 % faster than nt alone in six placements of the
+                    // output out of six (profiles/calib/r02_store_policy.jsonl), plain stores 2-6 % slower
+                    if (kTuningBuild && (a.flags & 56u)) {  // experiments: 1 plain, 2 nt, 4 sc0 nt
+                        if (a.flags & 8u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 0);
+                        else if (a.flags & 16u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 3);
+                    } else
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 18);
                 }
             } else {
     #pragma unroll
@@ -734,7 +741,7 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     }
     a.zStart[nChunks] = (uint32_t)nz;
     a.slotChunks = slot_chunks(s.ldsBytes, s.depth);
-    a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0);
+    a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0) | ((uint32_t)tuning("STAGE2_STORE", 0) << 3);  // STORE 1 plain, 2 nt, 4 sc0 nt (default: sc1 nt)
     a.nZChunks = tileMajor ? nChunks : 0u;
     const dim3 grid(tileMajor ? s.gridX * nChunks : s.gridX, tileMajor ? 1u : nChunks, 1);
     switch (plan.kind) {

@@ -25,7 +25,7 @@ def main():
     shutil.rmtree(work, ignore_errors=True)
     # --no-tune: the trace and the counters are those of ONE workgroup shape (the plan's default, or the second one with
     # --tuning-build and FIMEX_AMD_STAGE2_USE_ALT=1 in the environment), not a mix of the tuning launches
-    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--no-extras", "--no-tune"] + bargs
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--no-extras", "--no-tune", "--placements", "1"] + bargs
     r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", work + "/trace", "--"] + bench + ["--steps", "20", "--warmup", "3"])
     open(os.path.join(out, "%s_%s_bench.json" % (tag, name)), "w").write(r.stdout.strip().splitlines()[-1] + "\n")
     ks = glob.glob(work + "/trace/**/*_kernel_stats.csv", recursive=True)[0]

@@ -618,7 +618,11 @@ void launch_staged_t(const fimex_amd_regrid_plan& plan, StagedArgs& a, size_t nz
     if (zpb < 1) zpb = 1;
     if (zpb > nz) zpb = (uint32_t)nz;
     a.zPerBlock = zpb;
-    a.xcdRemap = (uint32_t)tuning("XCD", tileMajor ? 2 : 0);
+    // tile -> XCD map: stored types (1 and 2 bytes) with the 1 x 1 and 2 x 2 stencils run 3.5-4.3 % faster with tile rows dealt to the
+    // XCDs one by one (packed shorts, 200 slices: bilinear 1.71 -> 1.65 ms, nearest 1.56 -> 1.49 ms in three processes,
+    // profiles/r02_typed_order*.jsonl); floats and the 4 x 4 stencil keep the dispatch order
+    const bool rowsToXcds = tileMajor || (!std::is_same<T, float>::value && plan.kind != PlanKind::Bicubic);
+    a.xcdRemap = (uint32_t)tuning("XCD", rowsToXcds ? 2 : 0);
     a.ablate = (uint32_t)tuning("ABLATE", 0);
     a.storeAux = (uint32_t)tuning("STORE_AUX", 2);
     a.loadAux = (uint32_t)tuning("LOAD_AUX", 0);

@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-slice, copy and gather measurements")
     ap.add_argument("--placements", type=int, default=8,
                     help="positions of the output batch tried inside one larger allocation before the timed steps (1 = plain allocation)")
+    ap.add_argument("--placement-step-mib", type=int, default=704, help="distance between two tried positions of the output batch")
     ap.add_argument("--no-tune", action="store_true", help="keep the plan's default workgroup shape (skip fimex_amd_regrid_plan_tune_device)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of three output slices")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -264,7 +265,7 @@ def main():
     # time at the first position -- what a plain allocation would have got -- and at every other one are reported beside the metric.
     placement = None
     if args.placements > 1 and d_full is None:
-        step_floats = 704 * 1024 * 1024 // 4
+        step_floats = args.placement_step_mib * 1024 * 1024 // 4
         n_out = nz * out_layer
         del d_out
         arena = torch.empty(n_out + (args.placements - 1) * step_floats, dtype=torch.float32, device="cuda")
@@ -283,7 +284,7 @@ def main():
             tried.append(float(np.median(ts)))
         best = int(np.argmin(tried))
         d_out = arena[best * step_floats:best * step_floats + n_out].view(nz, wl.outY, wl.outX)
-        placement = {"positions": args.placements, "step_MiB": 704, "chosen": best, "ms_at_each": tried,
+        placement = {"positions": args.placements, "step_MiB": args.placement_step_mib, "chosen": best, "ms_at_each": tried,
                      "ms_at_first_position": tried[0], "note": "default workgroup shape, 3 launches each, before the shape tuning"}
 
     # the plan's two workgroup shapes (identical results) timed on this device and this batch, the faster kept: part of the product

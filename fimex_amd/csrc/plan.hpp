@@ -79,7 +79,8 @@ struct fimex_amd_regrid_plan {
     fimex_amd::DeviceArray<double> xfd, yfd;
     fimex_amd::StagedPlan staged;
     fimex_amd::Staged2Plan staged2;
-    // Second workgroup shape of the same plan (bilinear: 512 threads on 256 x 8 tiles next to 1024 threads on 512 x 8), same results
+    // Second workgroup shape of the same plan (bilinear: 512 threads on 256 x 8 tiles next to 1024 threads on 512 x 8; bicubic in float
+    // arithmetic: 256 threads on 128 x 8 next to 512 on 256 x 8), same results
     // bit for bit.  Which one is faster depends on the device at hand and on the batch length;
     // fimex_amd_regrid_plan_tune_device times both on the caller's buffers and sets useAlt.
     fimex_amd::Staged2Plan staged2Alt;

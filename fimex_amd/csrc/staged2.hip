@@ -680,6 +680,10 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     // slower on others and for short ones -- fimex_amd_regrid_plan_tune_device decides on the spot, the default stays
     if (plan.kind == PlanKind::Bilinear && plan.staged2.nt == 1024 && tuning("STAGE2_ALT", 1) != 0)
         build_staged2_shape(plan, plan.staged2Alt, 512, d_px, d_py, stream);
+    // likewise the 4 x 4 stencil in float arithmetic: 256 threads on 128 x 8 tiles (three workgroups per CU) beside 512 threads on
+    // 256 x 8 (2.38 against 2.41 ms in one process, profiles/r02_sweep_bicubicfast.log)
+    if (plan.kind == PlanKind::Bicubic && plan.bicubicFast && plan.staged2.nt == 512 && tuning("STAGE2_ALT", 1) != 0)
+        build_staged2_shape(plan, plan.staged2Alt, 256, d_px, d_py, stream);
     return true;
 }
 

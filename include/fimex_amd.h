@@ -157,7 +157,7 @@ int fimex_amd_regrid_apply_device(const fimex_amd_regrid_plan* plan,
                                   const float* d_in, size_t nz, float* d_out, void* stream);
 
 /**
- * Optional, no counterpart in the reference: a bilinear plan holds its LDS-staged form in two workgroup shapes with identical
+ * Optional, no counterpart in the reference: a bilinear plan (and a bicubic one with FIMEX_AMD_BICUBIC_FAST) holds its LDS-staged form in two workgroup shapes with identical
  * results, and which of them is faster depends on the device at hand and on the batch length.  This call regrids
  * the caller's nz slices a few times with each shape (d_out ends up holding the regridded slices), keeps the faster one for every
  * later apply of this plan and reports it in *chosenShape (0: the default shape, 1: the other; NULL allowed).  Plans without a

@@ -547,6 +547,15 @@ def test_plan_tune_keeps_results_and_both_shapes_match_the_oracle(fa, monkeypatc
         assert cases.same(d_out.cpu().numpy(), want), "shape %s: %s" % (forced, cases.describe_mismatch(d_out.cpu().numpy(), want))
     monkeypatch.delenv("FIMEX_AMD_STAGE2_USE_ALT")
     assert plan.tune_device(d_in.data_ptr(), 0, d_out.data_ptr(), st) == chosen  # nothing to time: the choice stands
+    # the 4 x 4 stencil in float arithmetic holds two shapes as well: the same bits from both
+    cub = fa.RegridPlan(oracle.BICUBIC, px, py, inX, inY, outX, outY, bicubic=fa.BICUBIC_FAST)
+    first = cub.apply_host(f)
+    assert cub.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), st) in (0, 1)
+    assert cases.same(d_out.cpu().numpy(), first)
+    for forced in ("0", "1"):
+        monkeypatch.setenv("FIMEX_AMD_STAGE2_USE_ALT", forced)
+        assert cases.same(cub.apply_host(f), first), "float bicubic, shape " + forced
+    monkeypatch.delenv("FIMEX_AMD_STAGE2_USE_ALT")
     near = fa.RegridPlan(oracle.NEAREST, px, py, inX, inY, outX, outY)
     assert near.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), st) == 0
     assert cases.same(near.apply_host(f), oracle.interpolate_values(oracle.NEAREST, px, py, f, inX, inY, outX, outY))

@@ -268,7 +268,12 @@ def main():
         step_floats = args.placement_step_mib * 1024 * 1024 // 4
         n_out = nz * out_layer
         del d_out
-        arena = torch.empty(n_out + (args.placements - 1) * step_floats, dtype=torch.float32, device="cuda")
+        try:
+            arena = torch.empty(n_out + (args.placements - 1) * step_floats, dtype=torch.float32, device="cuda")
+        except RuntimeError as e:  # no room for the larger allocation: the plain one
+            log("bench.py: no placement search (%s)" % str(e).splitlines()[0])
+            args.placements = 1
+            arena = torch.empty(n_out, dtype=torch.float32, device="cuda")
         tried = []
         for k in range(args.placements):
             view = arena[k * step_floats:k * step_floats + n_out]

@@ -153,6 +153,19 @@ struct Staged2Args {
     uint32_t flags;      // tuning build only: 1 no source loads, 2 no result stores
 };
 
+// Result stores of the slice loop: non-temporal and written through (sc1 nt): 0.4-1 % faster than nt alone in six placements of the
+// output out of six (profiles/calib/r02_store_policy.jsonl), plain stores 2-6 % slower.  Tuning build: flags 8 plain, 16 nt, 32 sc0 nt.
+__device__ __forceinline__ void store_result(uint32_t bits, rsrc_t ro, uint32_t off, uint32_t flags)
+{
+    if (kTuningBuild && (flags & 56u)) {
+        if (flags & 8u) __builtin_amdgcn_raw_buffer_store_b32(bits, ro, off, 0, 0);
+        else if (flags & 16u) __builtin_amdgcn_raw_buffer_store_b32(bits, ro, off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b32(bits, ro, off, 0, 3);
+        return;
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(bits, ro, off, 0, 18);
+}
+
 // STENCIL: 1 nearest, 2 bilinear, 4 bicubic; NT: threads of the workgroup; PER: outputs per lane (tile = NT * PER outputs);
 // KMAX: most 16-byte chunks a lane stages per slice.
 // FAST (bicubic only): the weights rounded to float and float fused multiply-adds instead of the reference's double products
@@ -364,7 +377,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                 for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float*>(curb + row[k][0]);
     #pragma unroll
                 for (int k = 0; k < PER; ++k)  // src/interpolation.c:869-876
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(PLAIN ? v[k] : pick(mUndef[k], undefined_f(), v[k])), ro, cellOff[k], 0, 2);
+                    store_result(__float_as_uint(PLAIN ? v[k] : pick(mUndef[k], undefined_f(), v[k])), ro, cellOff[k], a.flags);
             } else if constexpr (STENCIL == 2) {
                 float s00[PER], s01[PER], s10[PER], s11[PER];
     #pragma unroll
@@ -385,14 +398,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                         r = pick(mNnx[k], pick(mNny[k], s00[k], liny), pick(mNny[k], top, inter));
                         r = pick(mUndef[k], undefined_f(), r);
                     }
-                    // result stores: non-temporal and written through (sc1 nt): 0.4-1 % faster than nt alone in six placements of the
-                    // output out of six (profiles/calib/r02_store_policy.jsonl), plain stores 2-6 % slower
-                    if (kTuningBuild && (a.flags & 56u)) {  // experiments: 1 plain, 2 nt, 4 sc0 nt
-                        if (a.flags & 8u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 0);
-                        else if (a.flags & 16u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 2);
-                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 3);
-                    } else
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, cellOff[k], 0, 18);
+                    store_result(__float_as_uint(r), ro, cellOff[k], a.flags);
                 }
             } else {
     #pragma unroll
@@ -421,7 +427,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                             acc = (float)((double)acc + xmf * MY[k][r]);                    // :1019
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(PLAIN ? acc : pick(mUndef[k], undefined_f(), acc)), ro, cellOff[k], 0, 2);
+                    store_result(__float_as_uint(PLAIN ? acc : pick(mUndef[k], undefined_f(), acc)), ro, cellOff[k], a.flags);
                 }
             }
             if (more) wait_vmcnt<(DEPTH - 2) * UN + (DEPTH - 1) * PER>();

@@ -16,8 +16,13 @@ data-path collective -- the reference's MPI mode shards time steps the same way
     python bench.py --gpus N --steps K --warmup W      (N > 1 without WORLD_SIZE: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-After the timed steps slices 0, NZ/2 and NZ-1 of the last launch's output are compared bit for bit with the CPU
-oracle (outside the timed region); a mismatch makes the run fail.
+After the timed steps (outside the timed region) slices 0, NZ/2 and NZ-1 of the last launch's output are compared bit
+for bit with the CPU oracle, and EVERY slice of it with the same batch regridded once more by the per-lane gather kernels
+(fimex_amd_regrid_apply_gather_device) into a second buffer; a mismatch makes the run fail.
+
+The output batch is allocated by the library (fimex_amd_regrid_batch_alloc_device: the batch is tried at --placements windows of
+one reserved range, the fastest stays, the others' memory goes back to the driver); what a plain allocation would have got
+(the first window) and the cost of the probing are reported in config.output_placement.  --placements 1 = plain allocation.
 """
 import argparse
 import json
@@ -84,6 +89,31 @@ def verify_slices(torch, oracle_method, px, py, wl, d_in, d_out, first_slice, pi
                 same = (np.abs(got - want) <= tolerance * float(np.nanmax(np.abs(f)))) | (np.isnan(got) & np.isnan(want))
         if not bool(same.all()):
             bad.append((int(first_slice + k), int((~same).sum())))
+    return bad
+
+
+def verify_all_slices_vs_gather(torch, plan, d_in, d_out, nz, stream, tolerance=None):
+    """Every slice of the timed launch's output against the same batch regridded by the per-lane gather kernels (regrid.hip:
+    one lane per output cell reads its stencil from memory -- no tiles, no LDS ring, no DMA) into a second buffer, on the
+    device.  Bit for bit with NaNs at the same cells; tolerance given (FIMEX_AMD_BICUBIC_FAST: the gather kernel computes in
+    the reference's arithmetic): within that fraction of the batch's largest magnitude.  Returns the slices that differ."""
+    chk = torch.empty_like(d_out)
+    plan.apply_gather_device(d_in.data_ptr(), nz, chk.data_ptr(), stream)
+    torch.cuda.synchronize()
+    bad = []
+    lim = None
+    if tolerance is not None:
+        lim = tolerance * float(torch.nan_to_num(d_in[0], nan=0.0).abs().max().item() + 0.01 * nz)
+    for k0 in range(0, nz, 25):
+        a, b = d_out[k0:k0 + 25], chk[k0:k0 + 25]
+        both_nan = a.isnan() & b.isnan()
+        if lim is None:
+            same = (a.view(torch.int32) == b.view(torch.int32)) | both_nan
+        else:
+            same = ((a - b).abs() <= lim) | both_nan
+        per = same.flatten(1).all(dim=1)
+        bad += [int(k0 + i) for i in torch.nonzero(~per).flatten().tolist()]
+    del chk
     return bad
 
 
@@ -188,8 +218,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-slice, copy and gather measurements")
     ap.add_argument("--placements", type=int, default=8,
-                    help="positions of the output batch tried inside one larger allocation before the timed steps (1 = plain allocation)")
-    ap.add_argument("--placement-step-mib", type=int, default=704, help="distance between two tried positions of the output batch")
+                    help="windows the library tries for the output batch (fimex_amd_regrid_batch_alloc_device; 1 = plain allocation)")
+    ap.add_argument("--workload", default="default", choices=["default", "one_percent"],
+                    help="target axes: round 1's (10.9 %% of the target cells undefined) or the ~1 %% variant of SURVEY 8d")
     ap.add_argument("--no-tune", action="store_true", help="keep the plan's default workgroup shape (skip fimex_amd_regrid_plan_tune_device)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of three output slices")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -239,7 +270,7 @@ def main():
 
     method = {"bilinear": fa.BILINEAR, "bicubic": fa.BICUBIC, "nearest": fa.NEAREST_NEIGHBOR}[args.method]
     stencil = {"bilinear": 2, "bicubic": 4, "nearest": 1}[args.method]
-    wl = workloads.BilinearRotatedPole()
+    wl = workloads.BilinearRotatedPole(variant=args.workload)
     t0 = time.perf_counter()
     fast = args.bicubic_fast and args.method == "bicubic"
     plan, px, py = build_plan(fa, torch, wl, method, stream, bicubic=fa.BICUBIC_FAST if fast else None)
@@ -259,38 +290,30 @@ def main():
     d_full = torch.empty((nz_total, wl.outY, wl.outX), dtype=torch.float32, device="cuda") if (strong and rank == 0 and dist_on) else None
     d_out = d_full[first:last] if d_full is not None else torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    # Where the output batch lies in device memory moves this launch by up to 10 % (profiles/calib/r02_placement*.jsonl:
-    # same kernel, same traffic; cause not understood).  A resident pipeline allocates its output once, so it can afford what is done
-    # here: the batch is tried at --placements positions 704 MiB apart inside one larger allocation and stays at the fastest.  The
-    # time at the first position -- what a plain allocation would have got -- and at every other one are reported beside the metric.
+    # Where the output batch lies in device memory moves this launch by several per cent (same kernel, same traffic,
+    # per-channel request counts identical; profiles/calib/r03_placement_pmc_*.json).  The allocation is therefore a service of the
+    # library: fimex_amd_regrid_batch_alloc_device maps the batch at --placements windows of one reserved range, times the plan's
+    # apply on this source batch in each, keeps the fastest and returns the other windows' memory.  The time at the first
+    # window -- what a plain allocation would have got -- and the cost of the probing are reported beside the metric.
     placement = None
+    batch = None
     if args.placements > 1 and d_full is None:
-        step_floats = args.placement_step_mib * 1024 * 1024 // 4
-        n_out = nz * out_layer
         del d_out
+        torch.cuda.empty_cache()
         try:
-            arena = torch.empty(n_out + (args.placements - 1) * step_floats, dtype=torch.float32, device="cuda")
-        except RuntimeError as e:  # no room for the larger allocation: the plain one
+            batch = plan.alloc_batch(d_in.data_ptr(), nz, positions=args.placements, stream=stream)
+        except fa.FimexAmdError as e:  # the plain allocation instead
             log("bench.py: no placement search (%s)" % str(e).splitlines()[0])
-            args.placements = 1
-            arena = torch.empty(n_out, dtype=torch.float32, device="cuda")
-        tried = []
-        for k in range(args.placements):
-            view = arena[k * step_floats:k * step_floats + n_out]
-            ts = []
-            for r in range(4):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                plan.apply_device(d_in.data_ptr(), nz, view.data_ptr(), stream)
-                e1.record()
-                torch.cuda.synchronize()
-                if r > 0:
-                    ts.append(e0.elapsed_time(e1))
-            tried.append(float(np.median(ts)))
-        best = int(np.argmin(tried))
-        d_out = arena[best * step_floats:best * step_floats + n_out].view(nz, wl.outY, wl.outX)
-        placement = {"positions": args.placements, "step_MiB": args.placement_step_mib, "chosen": best, "ms_at_each": tried,
-                     "ms_at_first_position": tried[0], "note": "default workgroup shape, 3 launches each, before the shape tuning"}
+            d_out = torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
+    if batch is not None:
+        d_out = batch.as_tensor()
+        bi = batch.info
+        placement = {"by": "fimex_amd_regrid_batch_alloc_device", "positions": bi["positions"], "step_MiB": bi["stepBytes"] // (1 << 20),
+                     "chosen": bi["chosen"], "ms_at_each": bi["msAtPosition"],
+                     "ms_at_first_position": bi["msAtPosition"][0] if bi["msAtPosition"] else None,
+                     "bytes_mapped_while_probing": bi["bytesProbed"], "bytes_held_afterwards": bi["bytesHeld"], "batch_bytes": bi["bytes"],
+                     "other_windows_returned": bool(bi["trimmed"]), "probe_seconds": bi["probeSeconds"],
+                     "note": "default workgroup shape, median of 3 launches per window, before the shape tuning"}
 
     # the plan's two workgroup shapes (identical results) timed on this device and this batch, the faster kept: part of the product
     # (fimex_amd_regrid_plan_tune_device), done once per plan like the plan build and outside the timed steps
@@ -316,11 +339,14 @@ def main():
         failed = verify_slices(torch, {"bilinear": 1, "bicubic": 2, "nearest": 0}[args.method], px, py, wl, d_in, d_out, first, picks,
                                tolerance=1e-5 if fast else None)
         verified = [first + k for k in picks]
+        # ... and every slice of it against the gather kernels' result for the same batch (a second buffer, on the device)
+        bad_slices = verify_all_slices_vs_gather(torch, plan, d_in, d_out, nz, stream, tolerance=1e-5 if fast else None)
+        failed += [(first + k, -1) for k in bad_slices]
         flag = torch.tensor([len(failed)], dtype=torch.int64, device=comm_dev)
         if dist_on:
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) != 0:
-            log("bench.py: PARITY FAILURE on rank %d: (slice, differing cells) %r" % (rank, failed))
+            log("bench.py: PARITY FAILURE on rank %d: (slice, differing cells; -1 = differs from the gather kernels) %r" % (rank, failed))
             if dist_on:
                 dist.destroy_process_group()
             sys.exit(1)
@@ -363,7 +389,7 @@ def main():
             "sharding": "slices over GPUs, plan replicated, no data-path collective",
             "plan_build_s": t_plan, "tuned_shape": tuned_shape, "output_placement": placement, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
         },
-        "verified_slices": verified, "verified_how": "1e-5 of the slice's largest magnitude (FIMEX_AMD_BICUBIC_FAST)" if fast else "bit for bit against the CPU oracle",
+        "verified_slices": verified, "verified_all_slices_vs_gather": (not args.no_verify) or None, "verified_how": "1e-5 of the slice's largest magnitude (FIMEX_AMD_BICUBIC_FAST)" if fast else "bit for bit against the CPU oracle",
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_source,
@@ -377,18 +403,62 @@ def main():
     }
 
     if not args.no_extras:
-        # configs[1] proper: one time step, one slice (plan read not amortised over z)
+        # configs[1] proper: one time step, one slice per call (src/CDMInterpolator.cc:251-259 hands over a new slice every
+        # call).  Cold: the calls walk through the nz resident source / output slice pairs, so neither the L2s nor the 256 MB
+        # Infinity Cache hold any of the field from the previous call (the plan, read by every call, may stay there, as in a
+        # real run).  Warm: the same slice pair again and again -- cache resident, reported for comparison only.
+        # bytes of plan a one-slice call reads: batches below 4 slices take the gather kernels (pos + fractions per output cell)
+        plan_bytes_1 = {1: 4, 2: 12, 4: 20}[stencil] * out_layer
+        b1 = 4 * (n_src_bbox + out_layer) + plan_bytes_1
+        if nz >= 8:
+            ring = [(k * 7) % nz for k in range(max(3 * args.steps, 60))]
+            it = iter(ring * 2)
+
+            def one_cold():
+                k = next(it)
+                plan.apply_device(d_in.data_ptr() + 4 * in_layer * k, 1, d_out.data_ptr() + 4 * out_layer * k, stream)
+            _, kc1 = time_launches(torch, one_cold, len(ring), 5, False)
+            t1 = float(np.mean(kc1))
+            result["single_slice_cold"] = {
+                "workload": "configs[1], nz = 1, a different slice pair every call (%d pairs, %.1f GB working set)" % (nz, nz * 4e-9 * (in_layer + out_layer)),
+                "kernel_ms_avg": t1, "kernel_ms_min": float(np.min(kc1)), "Mcells_per_s": out_layer / (t1 * 1e-3) / 1e6,
+                "algorithmic_bytes": b1, "achieved_GBps": b1 / (t1 * 1e-3) / 1e9, "frac": b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "plan_bytes": plan_bytes_1}
         wall1, k1 = time_launches(torch, lambda: plan.apply_device(d_in.data_ptr(), 1, d_out.data_ptr(), stream),
                                   max(args.steps, 20), args.warmup, False)
-        b1 = 4 * (n_src_bbox + out_layer) + info["planBytes"]
-        result["single_slice"] = {"workload": "configs[1], nz = 1 (112 MB working set: served from the 256 MB Infinity Cache "
-                                              "when repeated, not from HBM)", "kernel_ms_avg": float(np.mean(k1)),
-                                  "Mcells_per_s": out_layer / (float(np.mean(k1)) * 1e-3) / 1e6,
-                                  "achieved_GBps": b1 / (float(np.mean(k1)) * 1e-3) / 1e9}
+        result["single_slice_warm"] = {"workload": "configs[1], nz = 1, the SAME slice pair every call: 112 MB working set, served from the "
+                                                   "256 MB Infinity Cache, not from HBM -- not a roofline figure", "kernel_ms_avg": float(np.mean(k1)),
+                                       "Mcells_per_s": out_layer / (float(np.mean(k1)) * 1e-3) / 1e6}
         # the box's copy ceiling for context: a device-to-device copy of the output's size, read + write bytes
         flat_in, flat_out = d_in.view(-1)[:d_out.numel()], d_out.reshape(-1)
         _, kc = time_launches(torch, lambda: flat_out.copy_(flat_in), 10, 2, False)
         result["roofline"]["copy_kernel_GBps"] = 8 * d_out.numel() / (float(np.mean(kc)) * 1e-3) / 1e9
+        if args.workload == "default" and args.method == "bilinear" and world == 1:
+            # the same source batch onto the target axes with ~1 % undefined cells (SURVEY 8d's proportions), beside the headline
+            try:
+                wl2 = workloads.BilinearRotatedPole(variant="one_percent")
+                plan2, px2, py2 = build_plan(fa, torch, wl2, method, stream)
+                shape2 = None if args.no_tune else plan2.tune_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream)
+                _, k2 = time_launches(torch, lambda: plan2.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), stream), args.steps, args.warmup, False)
+                bad2 = [] if args.no_verify else verify_slices(torch, 1, px2, py2, wl2, d_in, d_out, first, [0, nz - 1])
+                bad2 += [] if args.no_verify else [(k, -1) for k in verify_all_slices_vs_gather(torch, plan2, d_in, d_out, nz, stream)]
+                i2 = plan2.info()
+                n2 = workloads.reduced_domain_cells(px2, py2, wl2.inX, wl2.inY)
+                b2 = nz * 4 * (n2 + out_layer) + i2["planBytes"]
+                t2 = float(np.mean(k2))
+                result["one_percent_undefined_variant"] = {
+                    "workload": "same source batch, target rotated lon -8.8..8.8, lat 16.5..45.0: %.2f %% of the target cells undefined, reduced-domain "
+                                "bounding box %.1f %% of the source" % (100.0 * i2["undefinedCells"] / out_layer, 100.0 * n2 / in_layer),
+                    "kernel_ms_avg": t2, "Mcells_per_s": nz * out_layer / (t2 * 1e-3) / 1e6, "algorithmic_bytes_per_launch": b2, "n_src_bbox": n2,
+                    "frac": b2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "tuned_shape": shape2, "tile": [i2.get("tileW"), i2.get("tileH")],
+                    "verified": (not bad2) if not args.no_verify else None,
+                    "note": "output batch at the window chosen for the headline plan"}
+                if bad2:
+                    log("bench.py: PARITY FAILURE of the one_percent variant: %r" % (bad2,))
+                    sys.exit(1)
+                del plan2
+            except fa.FimexAmdError as e:
+                result["one_percent_undefined_variant"] = {"error": str(e)[:300]}
         step()  # d_out holds the regrid result again
         torch.cuda.synchronize()
         if dist_on:

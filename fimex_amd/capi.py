@@ -36,6 +36,15 @@ class PlanInfo(ctypes.Structure):
                 ("stagedCells", ctypes.c_size_t), ("tileW", ctypes.c_size_t), ("tileH", ctypes.c_size_t)]
 
 
+BATCH_MAX_POSITIONS = 16
+
+
+class BatchInfo(ctypes.Structure):
+    _fields_ = [("d_data", ctypes.c_void_p), ("bytes", ctypes.c_size_t), ("bytesProbed", ctypes.c_size_t), ("bytesHeld", ctypes.c_size_t),
+                ("stepBytes", ctypes.c_size_t), ("positions", ctypes.c_int), ("chosen", ctypes.c_int), ("trimmed", ctypes.c_int),
+                ("msAtPosition", ctypes.c_float * BATCH_MAX_POSITIONS), ("probeSeconds", ctypes.c_double)]
+
+
 class Process2d(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("relaxCrit", ctypes.c_float), ("corrEff", ctypes.c_float),
                 ("maxLoop", ctypes.c_size_t), ("repeat", ctypes.c_ushort), ("setWeight", ctypes.c_char),
@@ -66,6 +75,10 @@ SYMBOLS = {
     "fimex_amd_regrid_apply_host": (ctypes.c_int, [_V, _F, _Z, _F, _Z, _ZP]),
     "fimex_amd_regrid_apply_device": (ctypes.c_int, [_V, _V, _Z, _V, _V]),
     "fimex_amd_regrid_plan_tune_device": (ctypes.c_int, [_V, _V, _Z, _V, _V, ctypes.POINTER(ctypes.c_int)]),
+    "fimex_amd_regrid_apply_gather_device": (ctypes.c_int, [_V, _V, _Z, _V, _V]),
+    "fimex_amd_regrid_batch_alloc_device": (ctypes.c_int, [_V, _V, _Z, ctypes.c_int, _V, ctypes.POINTER(_V)]),
+    "fimex_amd_batch_get_info": (ctypes.c_int, [_V, ctypes.POINTER(BatchInfo)]),
+    "fimex_amd_batch_free": (ctypes.c_int, [_V]),
     "fimex_amd_regrid_slice_host": (ctypes.c_int, [_V, _F, _Z, ctypes.c_float, ctypes.POINTER(Process2d), _Z, _F, ctypes.c_float,
                                                    _V, ctypes.c_int, ctypes.POINTER(Process2d), _Z, _F, _Z, _ZP]),
     "fimex_amd_vector_plan_create": (ctypes.c_int, [_D, _Z, _Z, ctypes.POINTER(_V)]),
@@ -248,11 +261,57 @@ class RegridPlan:
     def apply_device(self, d_in, nz, d_out, stream=0):
         _check(load().fimex_amd_regrid_apply_device(self._h, d_in, nz, d_out, stream))
 
+    def apply_gather_device(self, d_in, nz, d_out, stream=0):
+        """The same regrid through the per-lane gather kernels (cross-check of the staged kernels on whole batches)."""
+        _check(load().fimex_amd_regrid_apply_gather_device(self._h, d_in, nz, d_out, stream))
+
+    def alloc_batch(self, d_in, nz, positions=8, stream=0):
+        """Output batch [nz][outY][outX] placed by the library (fimex_amd_regrid_batch_alloc_device)."""
+        return Batch(self, d_in, nz, positions, stream)
+
     def tune_device(self, d_in, nz, d_out, stream=0):
         """Times the plan's workgroup shapes on these device buffers and keeps the faster (0: default shape, 1: the other)."""
         chosen = ctypes.c_int(0)
         _check(load().fimex_amd_regrid_plan_tune_device(self._h, d_in, nz, d_out, stream, ctypes.byref(chosen)))
         return chosen.value
+
+
+class Batch:
+    """fimex_amd_batch: device memory of one output batch, placed where the plan's apply launch runs fastest."""
+
+    def __init__(self, plan, d_in, nz, positions=8, stream=0):
+        self._h = _V()
+        _check(load().fimex_amd_regrid_batch_alloc_device(plan._h, d_in, nz, positions, stream, ctypes.byref(self._h)))
+        i = BatchInfo()
+        _check(load().fimex_amd_batch_get_info(self._h, ctypes.byref(i)))
+        self.info = {k: getattr(i, k) for k, _ in BatchInfo._fields_ if k != "msAtPosition"}
+        self.info["msAtPosition"] = [float(i.msAtPosition[k]) for k in range(i.positions)] if i.positions > 1 else []
+        self.data_ptr = i.d_data
+        self.nz, self.outY, self.outX = nz, plan.outY, plan.outX
+
+    def as_tensor(self):
+        """The batch as a torch tensor [nz][outY][outX] (no copy; keep this object alive as long as the tensor)."""
+        import torch
+
+        class _Cai:  # __cuda_array_interface__ of library-owned device memory
+            pass
+        c = _Cai()
+        c.__cuda_array_interface__ = {"shape": (self.nz, self.outY, self.outX), "typestr": "<f4", "data": (int(self.data_ptr), False),
+                                      "version": 2, "strides": None}
+        t = torch.as_tensor(c, device="cuda")
+        t._fimex_amd_batch = self
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().fimex_amd_batch_free(self._h)
+            self._h = _V()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class VectorPlan:

@@ -73,6 +73,12 @@ void require_current_device(int planDevice)
                                       " but the calling thread's current device is " + std::to_string(dev));
 }
 
+void apply_plan_device(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    if (plan.kind == PlanKind::Forward) launch_forward_apply(plan, d_in, nz, d_out, stream);
+    else launch_backward_apply(plan, d_in, nz, d_out, stream);
+}
+
 namespace {
 
 bool is_backward(int funcType)
@@ -127,8 +133,7 @@ void build_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d
 
 void apply_device(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
 {
-    if (plan.kind == PlanKind::Forward) launch_forward_apply(plan, d_in, nz, d_out, stream);
-    else launch_backward_apply(plan, d_in, nz, d_out, stream);
+    apply_plan_device(plan, d_in, nz, d_out, stream);
 }
 
 // host <-> device round trip shared by the in-place *_host entry points
@@ -156,7 +161,7 @@ int fimex_amd_release_caches(void)
     return c_guard([&] { release_host_pipes(); });
 }
 
-int fimex_amd_abi_version(void) { return 120; }  // 1.20: plan constructors with the bicubic arithmetic, release of cached buffers
+int fimex_amd_abi_version(void) { return 130; }  // 1.30: output batches placed by the library, the gather cross-check
 
 int fimex_amd_device_count(void) { return usable_device_count(); }
 
@@ -282,7 +287,9 @@ int fimex_amd_regrid_plan_tune_device(fimex_amd_regrid_plan* plan, const float* 
     return c_guard([&] {
         FA_REQUIRE(plan != nullptr, "NULL plan");
         if (chosenShape) *chosenShape = plan->useAlt;
-        if (nz == 0 || !plan->staged2Alt.valid || !plan->staged2.valid) return;
+        // nothing to choose between: no second shape, or a batch that takes the gather kernels anyway (the choice made for the
+        // long batches stays as it is)
+        if (nz < staged_min_nz() || !plan->staged2Alt.valid || !plan->staged2.valid) return;
         FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
         require_current_device(plan->device);
         hipStream_t st = as_stream(stream);
@@ -322,6 +329,43 @@ int fimex_amd_regrid_plan_tune_device(fimex_amd_regrid_plan* plan, const float* 
         plan->info.tileH = s.tileH;
         if (chosenShape) *chosenShape = plan->useAlt;
     });
+}
+
+int fimex_amd_regrid_apply_gather_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream)
+{
+    return c_guard([&] {
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        FA_REQUIRE(plan->kind != PlanKind::Forward, "the gather kernels serve backward plans");
+        if (nz == 0) return;
+        FA_REQUIRE(d_in != nullptr && d_out != nullptr, "NULL device buffer");
+        require_current_device(plan->device);
+        launch_backward_gather(*plan, d_in, nz, d_out, as_stream(stream));
+    });
+}
+
+int fimex_amd_regrid_batch_alloc_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, int positions, void* stream,
+                                        fimex_amd_batch** batch)
+{
+    return c_guard([&] {
+        FA_REQUIRE(batch != nullptr, "batch output pointer is NULL");
+        *batch = nullptr;
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        require_current_device(plan->device);
+        *batch = batch_alloc(*plan, d_in, nz, positions, as_stream(stream));
+    });
+}
+
+int fimex_amd_batch_get_info(const fimex_amd_batch* batch, fimex_amd_batch_info* info)
+{
+    return c_guard([&] {
+        FA_REQUIRE(batch != nullptr && info != nullptr, "NULL argument");
+        *info = batch_info(*batch);
+    });
+}
+
+int fimex_amd_batch_free(fimex_amd_batch* batch)
+{
+    return c_guard([&] { batch_free(batch); });
 }
 
 int fimex_amd_vector_plan_create(const double* matrix, size_t ox, size_t oy, fimex_amd_vector_plan** out)

@@ -107,6 +107,7 @@ namespace fimex_amd {
 // regrid.hip
 void build_backward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
 void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+void launch_backward_gather(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 
 // staged.hip
 bool build_staged_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
@@ -169,6 +170,12 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
 void run_scan_sum(const float* d_values, size_t n, int mode, double average, int algo, double* h_sum, size_t* h_nUndefined,
                   hipStream_t stream);
 
+// batch.hip: output batches placed by the library
+fimex_amd_batch* batch_alloc(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, int positions, hipStream_t stream);
+void batch_free(fimex_amd_batch* batch);
+const fimex_amd_batch_info& batch_info(const fimex_amd_batch& batch);
+void apply_plan_device(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+
 // hostpipe.hip: streamed transfers for the *_host entry points
 using SliceChunkFn = std::function<void(const void* dRawIn, void* dRawOut, float* dFIn, float* dFOut, size_t nzc, hipStream_t stream)>;
 bool pipelined_slices(int device, const void* in, size_t inSliceBytes, void* out, size_t outSliceBytes, size_t inSliceFloats,
@@ -180,5 +187,9 @@ void release_host_pipes();
 
 // tuning knobs read once from the environment (FIMEX_AMD_<NAME>), for bench sweeps
 int tuning(const char* name, int fallback);
+
+// batches shorter than this take the gather kernels: the staged kernels pay a per-tile set-up (chunk list, per-output plan)
+// that only amortises over a few slices (launch_backward_apply and fimex_amd_regrid_plan_tune_device share the rule)
+inline size_t staged_min_nz() { return (size_t)tuning("STAGED_MIN_NZ", 4); }
 
 }  // namespace fimex_amd

@@ -612,14 +612,23 @@ void launch_backward_apply(const fimex_amd_regrid_plan& plan, const float* d_in,
     // the staged kernel pays a per-tile set-up (row table, chunk list) that only amortises over a few slices
     // (a bicubic plan in the reference's arithmetic that holds both forms runs the first one)
     const bool second = plan.staged2.valid && (plan.kind != PlanKind::Bicubic || plan.bicubicFast || !plan.staged.valid || tuning("STAGED2", 1) >= 2);
-    if (second && tuning("STAGED", 1) != 0 && tuning("STAGED2", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
+    if (second && tuning("STAGED", 1) != 0 && tuning("STAGED2", 1) != 0 && nz >= staged_min_nz()) {
         launch_staged2_apply(plan, d_in, nz, d_out, stream);
         return;
     }
-    if (plan.staged.valid && tuning("STAGED", 1) != 0 && nz >= (size_t)tuning("STAGED_MIN_NZ", 4)) {
+    if (plan.staged.valid && tuning("STAGED", 1) != 0 && nz >= staged_min_nz()) {
         launch_staged_apply(plan, d_in, nz, d_out, stream);
         return;
     }
+    launch_backward_gather(plan, d_in, nz, d_out, stream);
+}
+
+// The per-lane gather kernels on any backward plan (short batches, plans without a staged form, and the cross-check of
+// fimex_amd_regrid_apply_gather_device).
+void launch_backward_gather(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    if (nz == 0) return;
+    FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
     dim3 grid;
     const ApplyArgs a = make_args(plan, d_in, nz, d_out, grid);
     // a chunk of ZC slices is addressed through one 32-bit buffer range: fall back to ZC = 1 for huge slices
@@ -668,7 +677,7 @@ bool launch_typed_apply(const fimex_amd_regrid_plan& plan, const void* d_in, int
 {
     // 1- and 2-byte types through the LDS-staged kernels (the same dispatch rule as for floats)
     if (plan.kind != PlanKind::Forward && tuning("TYPED_FUSED", 1) != 0 && plan.staged.valid && tuning("STAGED", 1) != 0 && tuning("TYPED_STAGED", 1) != 0 &&
-        nz >= (size_t)tuning("STAGED_MIN_NZ", 4) && (plan.kind != PlanKind::Nearest || tuning("STAGED_NEAREST", 1) != 0) &&
+        nz >= staged_min_nz() && (plan.kind != PlanKind::Nearest || tuning("STAGED_NEAREST", 1) != 0) &&
         launch_staged_apply_typed(plan, d_in, cdmType, nz, badValue, d_out, stream))
         return true;
     // bicubic: the LDS-staged float kernel between two conversion passes beats a 16-load gather on the stored type

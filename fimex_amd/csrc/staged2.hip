@@ -608,7 +608,9 @@ bool build_shape(fimex_amd_regrid_plan& plan, Staged2Plan& s, const double* d_px
     uint32_t nStripes = (uint32_t)((nBands + stripe * kXcds / 2) / (stripe * kXcds)) * kXcds;
     if (nStripes < (uint32_t)kXcds) nStripes = kXcds;
     if (nStripes > nBands) nStripes = std::max<uint32_t>(nBands / kXcds * kXcds, 1);
-    for (size_t i = 0; i < tiles.size(); ++i) perXcd[((uint64_t)bandOf[i] * nStripes / nBands) % kXcds].push_back((uint32_t)i);
+    // (fewer tile rows than XCDs -- wide, short targets such as cross-sections: the tiles themselves are dealt round-robin)
+    for (size_t i = 0; i < tiles.size(); ++i)
+        perXcd[nBands < (uint32_t)kXcds ? i % kXcds : ((uint64_t)bandOf[i] * nStripes / nBands) % kXcds].push_back((uint32_t)i);
     size_t longest = 0;
     for (auto& l : perXcd) longest = std::max(longest, l.size());
     std::vector<uint32_t> order(longest * kXcds, 0xFFFFFFFFu);

@@ -167,6 +167,44 @@ int fimex_amd_regrid_apply_device(const fimex_amd_regrid_plan* plan,
 int fimex_amd_regrid_plan_tune_device(fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream,
                                       int* chosenShape);
 
+/**
+ * Cross-check, no counterpart in the reference: the same regrid through the per-lane gather kernels (one lane per output cell
+ * reads its stencil straight from memory) whatever LDS-staged form the plan holds.  Backward plans only.  The result equals
+ * fimex_amd_regrid_apply_device's bit for bit (FIMEX_AMD_BICUBIC_FAST plans: the reference's arithmetic, i.e. within the stated
+ * 1e-5); bench.py and the tests use it to check EVERY slice of a long batch on the device.
+ */
+int fimex_amd_regrid_apply_gather_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream);
+
+/* --------------------------------------- output batches placed by the library */
+/**
+ * The reference allocates the result of every interpolateValues call itself (src/CachedInterpolation.cc:123).  A caller that
+ * keeps its slices in device memory allocates the output batch [nz][outY][outX] once -- and where that batch lies in device
+ * memory moves the apply launch by several per cent.  This call allocates the batch for the caller: it maps it at
+ * `positions` windows (704 MiB apart) of one reserved address range, regrids the caller's source batch d_in into each window a
+ * few times with the plan's apply launch, keeps the fastest window and returns the physical memory of all others to the driver
+ * (HIP virtual memory management; where that is not available the whole range stays allocated, see bytesHeld).
+ * positions == 1: a plain allocation, nothing is timed (d_in may be NULL).  Fewer windows are tried when device memory is short.
+ * Synchronises the stream.  The batch holds the regridded slices of d_in afterwards only by accident: apply again.
+ */
+#define FIMEX_AMD_BATCH_MAX_POSITIONS 16
+typedef struct fimex_amd_batch fimex_amd_batch;
+typedef struct fimex_amd_batch_info {
+    void* d_data;        /* the batch: nz*outX*outY floats in device memory */
+    size_t bytes;        /* nz*outX*outY*4 */
+    size_t bytesProbed;  /* device memory mapped while the windows were tried */
+    size_t bytesHeld;    /* device memory behind this batch after the call (bytes rounded up to 32 MiB when trimmed) */
+    size_t stepBytes;    /* distance between two windows */
+    int positions;       /* windows tried */
+    int chosen;          /* the window that was kept */
+    int trimmed;         /* 1: the other windows' memory was returned */
+    float msAtPosition[FIMEX_AMD_BATCH_MAX_POSITIONS];  /* median time of the apply launch with the output in each window */
+    double probeSeconds; /* wall time of the whole call */
+} fimex_amd_batch_info;
+int fimex_amd_regrid_batch_alloc_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, int positions, void* stream,
+                                        fimex_amd_batch** batch);
+int fimex_amd_batch_get_info(const fimex_amd_batch* batch, fimex_amd_batch_info* info);
+int fimex_amd_batch_free(fimex_amd_batch* batch);
+
 /* ---------------------------------------------------------- vector rotation */
 /**
  * Opaque rotation plan.  Replaces CachedVectorReprojection

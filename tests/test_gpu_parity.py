@@ -83,6 +83,30 @@ def test_gather_and_lds_staged_paths_agree_with_oracle(fa, monkeypatch, method, 
     assert cases.same(got, want), cases.describe_mismatch(got, want)
 
 
+@pytest.mark.parametrize("method", [oracle.NEAREST, oracle.BILINEAR, oracle.BICUBIC])
+@pytest.mark.parametrize("outY", [5, 24, 40, 63])
+def test_wide_short_targets_use_every_xcd(fa, method, outY):
+    """Fewer tile rows than XCDs (a cross-section: outY < 8 tiles of 8 rows): the staged plan deals the tiles themselves over the
+    XCDs instead of putting all of them on one; results against the oracle, and the gather kernels agree on the device."""
+    import torch
+    inX, inY, outX, nz = 1600, 48, 2304, 9
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=outY, special=False)
+    f = cases.field(nz, inY, inX, seed=outY + 1)
+    want = oracle.interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    assert plan.info()["stagedCells"] > 0
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    d_in = torch.from_numpy(f).cuda()
+    a = torch.empty((nz, outY, outX), dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.apply_device(d_in.data_ptr(), nz, a.data_ptr(), st)
+    plan.apply_gather_device(d_in.data_ptr(), nz, b.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert cases.same(a.cpu().numpy(), want) and cases.same(b.cpu().numpy(), want)
+
+
 def test_bilinear_scattered_positions_fall_back_to_gather(fa):
     """Positions without spatial coherence (every tile would need the whole source): the staged plan does not fit
     its LDS budget and the plan silently keeps the gather kernel; results are the same."""

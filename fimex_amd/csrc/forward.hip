@@ -64,8 +64,10 @@ __device__ __forceinline__ bool keep(float v) { return UNDEF || !isnan(v); }
 // One bucket, ZC slices at a time: sum / mean / max / min (KIND 0 / 1 / 3 / 4) and the median of buckets of at most two
 // source cells (KIND 5: rank size()/2 of one value is the value, of two the larger one -- the second where they compare equal,
 // which is what counting "less, or equal and earlier" picks, src/CachedForwardInterpolation.cc:49-53).
+// i0: the bucket's first source cell, loaded once per lane outside the slice loop (most buckets hold one cell: no dependent
+// index load per slice group is left).
 template <int KIND, bool UNDEF, int ZC>
-__device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint32_t e, const float* src, const size_t (&koff)[ZC], float (&r)[ZC])
+__device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint32_t e, uint32_t i0, const float* src, const size_t (&koff)[ZC], float (&r)[ZC])
 {
     float acc[ZC], second[ZC];
     uint32_t cnt[ZC];
@@ -73,7 +75,7 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
 #pragma unroll
     for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; second[k] = 0.f; cnt[k] = 0; anyNan[k] = false; }
     for (uint32_t j = b; j < e; ++j) {
-        const uint32_t i = a.src[j];
+        const uint32_t i = (j == b) ? i0 : a.src[j];
         float v[ZC];
 #pragma unroll
         for (int k = 0; k < ZC; ++k) v[k] = src[koff[k] + i];
@@ -101,15 +103,20 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
     }
 }
 
-// one lane per target cell
+// one lane per target cell.  Workgroups are dealt round-robin over the 8 XCDs; XCD x takes the x-th eighth of the target
+// cells (blocks of 256 consecutive cells), so that a source line -- whose cells map to neighbouring targets in several target
+// rows -- is fetched into ONE L2 instead of into all eight (configs[3]: 1.85 GB -> about 1.1 GB of fabric traffic per 100 slices).
 template <int KIND, bool UNDEF, int ZC>
 __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 {
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t perXcd = gridDim.x / kXcds;  // the grid holds 8 * perXcd workgroups per z chunk
+    const uint32_t blk = (blockIdx.x % kXcds) * perXcd + blockIdx.x / kXcds;
+    const uint32_t t = blk * kBlock + threadIdx.x;
     if (t >= a.nOut) return;
     const uint32_t z0 = blockIdx.y * a.zPerBlock;
     const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
     const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
+    const uint32_t i0 = (e > b) ? a.src[b] : 0u;
     for (uint32_t z = z0; z < z1; z += ZC) {
         const float* src = a.in + (size_t)z * a.inLayer;
         // slices past the end of the chunk re-read the last one (results dropped): no branch in the gather loop
@@ -117,7 +124,7 @@ __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 #pragma unroll
         for (int k = 0; k < ZC; ++k) koff[k] = (size_t)min((uint32_t)k, z1 - 1 - z) * a.inLayer;
         float r[ZC];
-        reduce_bucket<KIND, UNDEF, ZC>(a, b, e, src, koff, r);
+        reduce_bucket<KIND, UNDEF, ZC>(a, b, e, i0, src, koff, r);
 #pragma unroll
         for (int k = 0; k < ZC; ++k)
             if (z + k < z1) __builtin_nontemporal_store(r[k], a.out + (size_t)(z + k) * a.nOut + t);
@@ -238,6 +245,8 @@ __global__ void __launch_bounds__(kBlock) forward_apply_wave(FwdArgs a)
     }
 }
 
+constexpr int kLaneZc = 8;  // slices a lane reduces together (gathers in flight per lane)
+
 template <int KIND, bool UNDEF>
 void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, hipStream_t stream)
 {
@@ -245,7 +254,7 @@ void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, hipStream_t stream)
         dim3 g((uint32_t)ceil_div(a.nOut, kBlock / kWave), grid.y, 1);
         forward_apply_wave<KIND, UNDEF><<<g, kBlock, 0, stream>>>(a);
     } else {
-        forward_apply_lane<KIND, UNDEF, 4><<<grid, kBlock, 0, stream>>>(a);
+        forward_apply_lane<KIND, UNDEF, kLaneZc><<<grid, kBlock, 0, stream>>>(a);
     }
 }
 
@@ -341,12 +350,19 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.nOut = (uint32_t)(plan.outX * plan.outY);
     a.inLayer = plan.inX * plan.inY;
     a.nz = (uint32_t)nz;
-    uint32_t zpb = (uint32_t)tuning("FWD_ZPB", 8);
+    // z chunks: a workgroup reads its CSR entries once per chunk, so chunks are long (the CSR of configs[3] is 10 MB, a slice's
+    // must-move bytes about the same); several chunks only where the target grid alone would not fill the chip
+    const size_t blocks = ceil_div(a.nOut, kBlock);
+    uint32_t zpb = (uint32_t)tuning("FWD_ZPB", blocks >= 4096 ? 64 : 16);
     if (zpb > nz) zpb = (uint32_t)nz;
+    size_t chunks = ceil_div(nz, (size_t)zpb);
+    zpb = (uint32_t)ceil_div(nz, chunks);  // chunks of one size
     a.zPerBlock = zpb;
-    const size_t chunks = ceil_div(nz, (size_t)zpb);
+    chunks = ceil_div(nz, (size_t)zpb);
     FA_REQUIRE(chunks <= 65535, "too many z chunks for one launch");
     const dim3 grid((uint32_t)ceil_div(a.nOut, kBlock), (uint32_t)chunks, 1);
+    // the lane kernels map workgroup -> block of targets through the XCD it runs on: their grid is a multiple of 8
+    const dim3 gridLane((uint32_t)(ceil_div(blocks, (size_t)kXcds) * kXcds), (uint32_t)chunks, 1);
     // mean bucket length decides: long buckets are reduced by a whole wave
     const size_t nonEmpty = a.nOut - plan.info.undefinedCells;
     const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
@@ -354,15 +370,15 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     const bool wavePath = (waveMode < 0) ? (meanBucket >= 32.0) : (waveMode != 0);
     const bool u = plan.undefAggr;
     switch (plan.aggregate) {
-    case Aggregate::Sum: u ? launch_kind<0, true>(a, grid, wavePath, stream) : launch_kind<0, false>(a, grid, wavePath, stream); break;
-    case Aggregate::Mean: u ? launch_kind<1, true>(a, grid, wavePath, stream) : launch_kind<1, false>(a, grid, wavePath, stream); break;
-    case Aggregate::Max: u ? launch_kind<3, true>(a, grid, wavePath, stream) : launch_kind<3, false>(a, grid, wavePath, stream); break;
-    case Aggregate::Min: u ? launch_kind<4, true>(a, grid, wavePath, stream) : launch_kind<4, false>(a, grid, wavePath, stream); break;
+    case Aggregate::Sum: u ? launch_kind<0, true>(a, gridLane, wavePath, stream) : launch_kind<0, false>(a, gridLane, wavePath, stream); break;
+    case Aggregate::Mean: u ? launch_kind<1, true>(a, gridLane, wavePath, stream) : launch_kind<1, false>(a, gridLane, wavePath, stream); break;
+    case Aggregate::Max: u ? launch_kind<3, true>(a, gridLane, wavePath, stream) : launch_kind<3, false>(a, gridLane, wavePath, stream); break;
+    case Aggregate::Min: u ? launch_kind<4, true>(a, gridLane, wavePath, stream) : launch_kind<4, false>(a, gridLane, wavePath, stream); break;
     case Aggregate::Median:
         if (plan.info.maxBucket <= 2 && tuning("FWD_MEDIAN_SHORT", 1) != 0) {  // no bucket holds more than two cells: four slices in flight, no rank counting
             // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
-            if (u) forward_apply_lane<5, true, 4><<<grid, kBlock, 0, stream>>>(a);
-            else forward_apply_lane<5, false, 4><<<grid, kBlock, 0, stream>>>(a);
+            if (u) forward_apply_lane<5, true, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
+            else forward_apply_lane<5, false, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
         } else if (u) forward_apply_median<true><<<grid, kBlock, 0, stream>>>(a);
         else forward_apply_median<false><<<grid, kBlock, 0, stream>>>(a);
         break;

@@ -21,6 +21,7 @@
 #include "common.hpp"
 
 #include <functional>
+#include <mutex>
 
 namespace fimex_amd {
 
@@ -87,6 +88,15 @@ struct fimex_amd_regrid_plan {
     int useAlt = 0;
     size_t planBytesShape[2] = {0, 0};  // info.planBytes with either shape
 
+    // The second staged form for slices of 1- and 2-byte stored types (staged2.hip): built from this plan's own arrays on the
+    // first typed apply of that element size, under the mutex (plans are shared by threads; everything else is immutable).
+    struct TypedForms {
+        std::mutex mtx;
+        bool tried[2] = {false, false};  // [0] 2-byte elements, [1] 1-byte elements
+        fimex_amd::Staged2Plan form[2];
+    };
+    mutable TypedForms typed2;
+
     // forward plans
     fimex_amd::Aggregate aggregate = fimex_amd::Aggregate::Sum;
     bool undefAggr = false;
@@ -118,6 +128,8 @@ bool launch_staged_apply_typed(const fimex_amd_regrid_plan& plan, const void* d_
 // staged2.hip
 bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
 void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+bool launch_staged2_apply_typed(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                                hipStream_t stream);
 
 // forward.hip
 void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);

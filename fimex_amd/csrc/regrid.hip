@@ -285,6 +285,69 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply(ApplyArgs a, const uint
     }
 }
 
+// Fewer slices than the staged kernels need (nz < 4): one time step of a variable without levels, the reference's call pattern
+// for surface fields (src/CDMInterpolator.cc:251-259).  There is no slice loop to keep loads in flight across, and a lane with
+// one output cell spends its life in two dependent round trips to memory (plan entry, then stencil).  Here a lane takes CELLS
+// output cells of a 64 x (4 * CELLS) tile (rows y, y + 4, ...): the plan entries of all of them are loaded first, then all
+// their stencil values -- four times the bytes in flight per lane; border and undefined cells are computed by selection
+// (every form evaluated, src/interpolation.c:899-948), so that no lane leaves the common path.  STENCIL 1: nearest (:869-876).
+template <int STENCIL, int CELLS>
+__global__ void __launch_bounds__(kBlock) apply_few(ApplyArgs a, const uint32_t* __restrict__ pos, const float* __restrict__ xfrac,
+                                                    const float* __restrict__ yfrac, uint32_t tilesX, uint32_t nTiles, uint32_t tilesPerXcd)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = (b % kXcds) * tilesPerXcd + b / kXcds;  // a contiguous band of tile rows per XCD
+    if (tile >= nTiles) return;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t x = tx * 64u + (threadIdx.x & 63u);
+    const uint32_t y0 = ty * (4u * CELLS) + (threadIdx.x >> 6);
+    uint32_t cb[CELLS], pb[CELLS], dxb[CELLS], dyb[CELLS];
+    float xf[CELLS], yf[CELLS];
+    bool undef[CELLS], nnx[CELLS], nny[CELLS];
+#pragma unroll
+    for (int k = 0; k < CELLS; ++k) {
+        const uint32_t y = y0 + 4u * k;
+        const bool mine = x < a.outX && y < a.outY;
+        const uint32_t cell = y * a.outX + x;
+        cb[k] = mine ? cell * 4u : 0xFFFFFFFFu;  // beyond the slice: the store is dropped
+        const uint32_t p = mine ? pos[cell] : kInvalidPos;
+        xf[k] = (mine && STENCIL == 2) ? xfrac[cell] : 0.f;
+        yf[k] = (mine && STENCIL == 2) ? yfrac[cell] : 0.f;
+        undef[k] = p == kInvalidPos;
+        pb[k] = undef[k] ? 0u : p * 4u;
+        nnx[k] = (__float_as_uint(xf[k]) >> 31) != 0;
+        nny[k] = (__float_as_uint(yf[k]) >> 31) != 0;
+        dxb[k] = nnx[k] ? 0u : 4u;           // a missing neighbour repeats the cell itself (its value is not used)
+        dyb[k] = nny[k] ? 0u : a.ix * 4u;
+    }
+    const uint32_t inBytes = (uint32_t)a.inLayer * 4u, outBytes = a.nOut * 4u;
+    for (uint32_t z = 0; z < a.nz; ++z) {
+        const rsrc_t rs = make_rsrc(a.in + (size_t)z * a.inLayer, inBytes), ro = make_rsrc(a.out + (size_t)z * a.nOut, outBytes);
+        float s00[CELLS], s01[CELLS], s10[CELLS], s11[CELLS];
+#pragma unroll
+        for (int k = 0; k < CELLS; ++k) {
+            s00[k] = ld(rs, pb[k], 0);
+            if (STENCIL == 2) {
+                s01[k] = ld(rs, pb[k] + dxb[k], 0);
+                s10[k] = ld(rs, pb[k] + dyb[k], 0);
+                s11[k] = ld(rs, pb[k] + dxb[k] + dyb[k], 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CELLS; ++k) {
+            float r = s00[k];
+            if (STENCIL == 2) {
+                const float top = (1.f - xf[k]) * s00[k] + xf[k] * s01[k];   // :911 when nearest in y
+                const float bot = (1.f - xf[k]) * s10[k] + xf[k] * s11[k];
+                const float inter = (1.f - yf[k]) * top + yf[k] * bot;       // :899-900
+                const float liny = (1 - yf[k]) * s00[k] + (yf[k] * s10[k]);  // :931
+                r = nnx[k] ? (nny[k] ? s00[k] : liny) : (nny[k] ? top : inter);
+            }
+            st_stream(ro, cb[k], 0, undef[k] ? undefined_f() : r);
+        }
+    }
+}
+
 // Keys kernel a = -0.5: rows of M/2 (src/interpolation.c:962-968), weights XM / MY (:977-1000)
 __device__ __forceinline__ void cubic_weights(double f, double w[4])
 {
@@ -631,6 +694,17 @@ void launch_backward_gather(const fimex_amd_regrid_plan& plan, const float* d_in
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
     dim3 grid;
     const ApplyArgs a = make_args(plan, d_in, nz, d_out, grid);
+    if (nz < staged_min_nz() && plan.kind != PlanKind::Bicubic && tuning("FEW", 1) != 0) {
+        // one or a few slices: four output cells per lane (apply_few)
+        constexpr int kCells = 4;
+        const uint32_t tilesX = (uint32_t)ceil_div(plan.outX, (size_t)64), tilesY = (uint32_t)ceil_div(plan.outY, (size_t)(4 * kCells));
+        const uint32_t nTiles = tilesX * tilesY, perXcd = (uint32_t)ceil_div(nTiles, kXcds);
+        const dim3 g(perXcd * kXcds);
+        if (plan.kind == PlanKind::Nearest) apply_few<1, kCells><<<g, kBlock, 0, stream>>>(a, plan.pos.get(), nullptr, nullptr, tilesX, nTiles, perXcd);
+        else apply_few<2, kCells><<<g, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get(), tilesX, nTiles, perXcd);
+        FA_HIP(hipGetLastError());
+        return;
+    }
     // a chunk of ZC slices is addressed through one 32-bit buffer range: fall back to ZC = 1 for huge slices
     const size_t sliceBytes = 4 * (a.inLayer > a.nOut ? a.inLayer : (size_t)a.nOut);
     auto fits = [&](size_t zc) { return sliceBytes * zc <= 0xFFFFFFFFull; };
@@ -675,7 +749,11 @@ void launch_backward_gather(const fimex_amd_regrid_plan& plan, const float* d_in
 bool launch_typed_apply(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
                         hipStream_t stream)
 {
-    // 1- and 2-byte types through the LDS-staged kernels (the same dispatch rule as for floats)
+    // 1- and 2-byte types through the LDS-staged kernels (the same dispatch rule as for floats): the second staged form
+    // (staged2.hip, nearest and bilinear), else the first one
+    if (plan.kind != PlanKind::Forward && tuning("TYPED_FUSED", 1) != 0 && tuning("STAGED", 1) != 0 && tuning("TYPED_STAGED", 1) != 0 &&
+        tuning("TYPED_STAGED2", 1) != 0 && nz >= staged_min_nz() && launch_staged2_apply_typed(plan, d_in, cdmType, nz, badValue, d_out, stream))
+        return true;
     if (plan.kind != PlanKind::Forward && tuning("TYPED_FUSED", 1) != 0 && plan.staged.valid && tuning("STAGED", 1) != 0 && tuning("TYPED_STAGED", 1) != 0 &&
         nz >= staged_min_nz() && (plan.kind != PlanKind::Nearest || tuning("STAGED_NEAREST", 1) != 0) &&
         launch_staged_apply_typed(plan, d_in, cdmType, nz, badValue, d_out, stream))

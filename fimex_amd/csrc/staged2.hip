@@ -17,6 +17,7 @@
 //   * tile rows are dealt to the XCDs in stripes (neighbours in x share an L2) through a workgroup -> tile table.
 #include "plan.hpp"
 #include "staged_common.hpp"
+#include "typed_convert.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -28,11 +29,41 @@ namespace {
 
 // One workgroup per tile.  emit == 0: counts the 16-byte chunks of the tile's row segments (tiles[t].nChunks, ~0u = does not
 // fit).  emit == 1: writes the chunk list and every output cell's LDS offsets (16 bits per stencil row, in floats).
+// Where the stencil of an output cell lies: from the caller's positions (plan creation), or -- for the forms of stored types,
+// which are built on first use, long after the positions are gone -- from the gather plan the positions were turned into
+// (regrid.hip: pos = first cell of the stencil, the sign bits of xf / yf = "one column" / "one row", src/interpolation.c:903-948).
+struct NeedSource {
+    const double* px = nullptr;
+    const double* py = nullptr;
+    const uint32_t* pos = nullptr;
+    const float* xf = nullptr;
+    const float* yf = nullptr;
+};
+
 template <int STENCIL>
-__global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ px, const double* __restrict__ py, int64_t ix, int64_t iy,
+__device__ __forceinline__ CellNeed need_of(const NeedSource& n, size_t cell, int64_t ix, int64_t iy)
+{
+    if (n.px != nullptr) return classify<STENCIL>(n.px[cell], n.py[cell], ix, iy);
+    CellNeed c{};
+    const uint32_t p = n.pos[cell];
+    c.valid = p != kInvalidPos;
+    if (!c.valid) return c;
+    c.ya = (int64_t)(p / (uint32_t)ix);
+    c.xa = (int64_t)p - c.ya * ix;
+    if (STENCIL == 1) { c.xb = c.xa; c.yb = c.ya; }
+    else if (STENCIL == 2) {
+        c.xb = c.xa + ((__float_as_uint(n.xf[cell]) >> 31) ? 0 : 1);
+        c.yb = c.ya + ((__float_as_uint(n.yf[cell]) >> 31) ? 0 : 1);
+    } else { c.xb = c.xa + 3; c.yb = c.ya + 3; }
+    return c;
+}
+
+// cpc: source cells per 16-byte chunk (4 for float slices, 8 / 16 for slices of 2- / 1-byte elements); LDS offsets count elements.
+template <int STENCIL>
+__global__ void __launch_bounds__(kBlock) tile_scan(NeedSource need, int64_t ix, int64_t iy,
                                                     uint32_t outX, uint32_t outY, uint32_t tileH, StagedTile* __restrict__ tiles,
                                                     uint32_t capChunks, int emit, uint32_t* __restrict__ chunkOff,
-                                                    uint32_t* __restrict__ ldsA, uint32_t* __restrict__ ldsB)
+                                                    uint32_t* __restrict__ ldsA, uint32_t* __restrict__ ldsB, uint32_t cpc)
 {
     __shared__ int shRmin, shRmax, shFail;
     __shared__ int rowMin[kMaxRows], rowMax[kMaxRows];
@@ -47,7 +78,7 @@ __global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ p
         const uint32_t y = T.y0 + e / T.w, x = T.x0 + e % T.w;
         if (y >= outY) continue;
         const size_t cell = (size_t)y * outX + x;
-        const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+        const CellNeed c = need_of<STENCIL>(need, cell, ix, iy);
         if (c.valid) { atomicMin(&shRmin, (int)c.ya); atomicMax(&shRmax, (int)c.yb); }
     }
     __syncthreads();
@@ -63,7 +94,7 @@ __global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ p
         const uint32_t y = T.y0 + e / T.w, x = T.x0 + e % T.w;
         if (y >= outY) continue;
         const size_t cell = (size_t)y * outX + x;
-        const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+        const CellNeed c = need_of<STENCIL>(need, cell, ix, iy);
         if (c.valid)
             for (int64_t r = c.ya; r <= c.yb; ++r) {
                 atomicMin(&rowMin[r - rmin], (int)c.xa);
@@ -80,10 +111,11 @@ __global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ p
                 // the segment starts on a 16-byte boundary of the SLICE (the DMA moves 16 bytes per lane; aligned pieces stay
                 // inside one line): it may begin up to 3 cells before the first cell needed, in the row above for x < 0
                 const int64_t first = (int64_t)(rmin + i) * ix + rowMin[i];
-                int64_t start = first & ~(int64_t)3;
-                const uint32_t nch = (uint32_t)((first - start + (rowMax[i] - rowMin[i])) / 4 + 1);
-                // a last chunk that would cross the end of the slice is moved back instead (unaligned, still whole)
-                if (start + 4 * (int64_t)nch > layer) start = layer - 4 * (int64_t)nch;
+                int64_t start = first & ~(int64_t)(cpc - 1);
+                const uint32_t nch = (uint32_t)((first - start + (rowMax[i] - rowMin[i])) / cpc + 1);
+                // a last chunk that would cross the end of the slice is moved back instead (unaligned, still whole; slices of
+                // stored types hold a multiple of 4 bytes, so the chunk still starts on a 4-byte boundary)
+                if (start + cpc * (int64_t)nch > layer) start = layer - cpc * (int64_t)nch;
                 if (start < 0) shFail = 1;
                 rowMin[i] = (int)(start - (int64_t)(rmin + i) * ix);  // column of the segment's first cell, may be negative
                 acc += nch;
@@ -104,20 +136,20 @@ __global__ void __launch_bounds__(kBlock) tile_scan(const double* __restrict__ p
             const uint32_t mid = (lo + hi + 1) >> 1;
             if (rowChunk[mid] <= c) lo = mid; else hi = mid - 1;
         }
-        chunkOff[T.chunkBase + c] = (uint32_t)((int64_t)(rmin + (int)lo) * ix + rowMin[lo] + 4 * (int64_t)(c - rowChunk[lo]));
+        chunkOff[T.chunkBase + c] = (uint32_t)((int64_t)(rmin + (int)lo) * ix + rowMin[lo] + cpc * (int64_t)(c - rowChunk[lo]));
     }
     for (uint32_t e = threadIdx.x; e < nCells; e += kBlock) {
         const uint32_t y = T.y0 + e / T.w, x = T.x0 + e % T.w;
         if (y >= outY) continue;
         const size_t cell = (size_t)y * outX + x;
-        const CellNeed c = classify<STENCIL>(px[cell], py[cell], ix, iy);
+        const CellNeed c = need_of<STENCIL>(need, cell, ix, iy);
         uint32_t a = kInvalidPos, b = kInvalidPos;
         if (c.valid) {
             uint32_t off[4];
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = (c.ya + r <= c.yb) ? c.ya + r : c.yb;  // missing rows repeat the last one
                 const int i = (int)(row - rmin);
-                off[r] = rowChunk[i] * 4 + (uint32_t)(c.xa - rowMin[i]);
+                off[r] = rowChunk[i] * cpc + (uint32_t)(c.xa - rowMin[i]);
             }
             a = off[0] | (off[1] << 16);
             b = off[2] | (off[3] << 16);
@@ -454,6 +486,310 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
     }
 }
 
+// ---- the same scheme on a variable's STORED type (data2InterpolationArray + interpolateValues +
+// interpolationArray2Data of src/CDMInterpolator.cc:115-124, 251-285 in one kernel): slices of 1- or 2-byte integers.
+// The plan form is its own (built on first use, staged2_typed_form): a 16-byte chunk holds 8 or 16 source cells, LDS offsets
+// count elements.  Differences to the float kernel: a lane owns two PAIRS of neighbouring outputs (cells 2 * t, 2 * t + 1 of
+// the tile, and the same NT * 2 cells further on), so that two results leave in one 4-byte (2-byte elements) or 2-byte store
+// and a wave still writes 256 (128) contiguous bytes; the two source elements of a stencil row arrive in one ds_read2_b32 and
+// are shifted apart; elements become float / NaN as Data::asFloat + mifi_bad2nanf do, results go back through ScaleValue's
+// rounding (typed_convert.hpp).
+struct TypedEdge {
+    float bad;          // the variable's fill value narrowed to float (mifi_bad2nanf's argument)
+    uint32_t hasBad;
+    double fillOut;     // NaN -> this (interpolationArray2Data)
+    uint32_t pairStore; // outX even: the two results of a pair share one store
+};
+
+// two neighbouring 1- or 2-byte elements at element offset `byteOff / sizeof(T)` of the staged image
+// (alignedOff = byteOff & ~3; shift = byteOff * 8: v_alignbit_b32 takes the low five bits, (byteOff & 3) * 8 -- both are
+// computed once per lane, outside the slice loop)
+template <typename T>
+__device__ __forceinline__ void lds_pair2(const char* buf, uint32_t alignedOff, uint32_t shift, float bad, bool hasBad, float& first, float& second)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(buf + alignedOff);
+    const uint32_t both = __builtin_amdgcn_alignbit(w[1], w[0], shift);
+    if constexpr (sizeof(T) == 2) {
+        first = as_float_nan((T)(unsigned short)(both & 0xffffu), bad, hasBad);
+        second = as_float_nan((T)(unsigned short)(both >> 16), bad, hasBad);
+    } else {
+        first = as_float_nan((T)(unsigned char)(both & 0xffu), bad, hasBad);
+        second = as_float_nan((T)(unsigned char)((both >> 8) & 0xffu), bad, hasBad);
+    }
+}
+template <typename T>
+__device__ __forceinline__ float lds_one(const char* buf, uint32_t byteOff, float bad, bool hasBad)
+{
+    return as_float_nan(*reinterpret_cast<const T*>(buf + byteOff), bad, hasBad);
+}
+// the two elements as they are stored, converted but not yet compared with the fill value (the interior form tests all four
+// stencil values at once: any fill value among them makes the result undefined, whatever its weight -- 0 * NaN is NaN)
+template <typename T>
+__device__ __forceinline__ void lds_pair2_raw(const char* buf, uint32_t alignedOff, uint32_t shift, float& first, float& second)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(buf + alignedOff);
+    const uint32_t both = __builtin_amdgcn_alignbit(w[1], w[0], shift);
+    if constexpr (sizeof(T) == 2) {
+        first = (float)(T)(unsigned short)(both & 0xffffu);
+        second = (float)(T)(unsigned short)(both >> 16);
+    } else {
+        first = (float)(T)(unsigned char)(both & 0xffu);
+        second = (float)(T)(unsigned char)((both >> 8) & 0xffu);
+    }
+}
+// interpolationArray2Data for results of THIS kernel: NaN -> fill, else MetNoFimex::round (lround) and the reference's casts
+// long -> int -> T (typed_convert.hpp: from_float_fill).  The results here are stored elements or convex combinations of four
+// of them, so |v| < 2^17: the branch of from_float_fill for values beyond the int range cannot be taken and is left out, the
+// rest is the same arithmetic without branches (the fraction v - trunc(v) is exact in float).
+template <typename T>
+__device__ __forceinline__ uint32_t round_bits(float v, T fill)
+{
+    const float t = truncf(v);
+    const float r = t + ((fabsf(v - t) >= 0.5f) ? copysignf(1.f, v) : 0.f);
+    const int i = (v != v) ? (int)fill : (int)r;
+    return (uint32_t)i;
+}
+// results r0 (cell c) and r1 (cell c + 1) of one pair; offsets in BYTES of the typed slice, ~0u = not mine
+template <typename T, bool PAIR>
+__device__ __forceinline__ void store_pair(rsrc_t ro, uint32_t off0, uint32_t off1, float r0, float r1, T fill)
+{
+    constexpr uint32_t kMask = sizeof(T) == 2 ? 0xffffu : 0xffu;
+    const uint32_t b0 = round_bits<T>(r0, fill) & kMask, b1 = round_bits<T>(r1, fill) & kMask;
+    if constexpr (PAIR) {  // both cells exist or neither (even row length, even tile widths)
+        if constexpr (sizeof(T) == 2) __builtin_amdgcn_raw_buffer_store_b32(b0 | (b1 << 16), ro, off0, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(b0 | (b1 << 8)), ro, off0, 0, 2);
+        (void)off1;
+    } else if constexpr (sizeof(T) == 2) {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b0, ro, off0, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b1, ro, off1, 0, 2);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b0, ro, off0, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b1, ro, off1, 0, 2);
+    }
+}
+
+// STENCIL 1 (nearest) or 2 (bilinear); NT threads, 4 outputs per lane (two pairs); KMAX 16-byte chunks per lane and slice
+// PAIR: the row length and the slice start allow aligned stores of two results
+template <int STENCIL, int NT, int KMAX, typename T, bool PAIR, int DEPTH = 2>
+__global__ void __launch_bounds__(NT) staged_apply2_typed(Staged2Args a, TypedEdge te)
+{
+    static_assert(STENCIL == 1 || STENCIL == 2, "stored types: nearest and bilinear");
+    constexpr uint32_t EB = sizeof(T);
+    constexpr int PER = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint32_t slot0 = blockIdx.x, zc = blockIdx.y;
+    if (a.nZChunks != 0) {
+        const uint32_t k = blockIdx.x / kXcds;
+        zc = k % a.nZChunks;
+        slot0 = (k / a.nZChunks) * kXcds + blockIdx.x % kXcds;
+    }
+    const uint32_t tile = a.order[slot0];
+    if (tile == 0xFFFFFFFFu) return;
+    const StagedTile T_ = a.tiles[tile];
+    const uint32_t z0 = a.zStart[zc], z1 = a.zStart[zc + 1];
+    const uint32_t nzl = z1 - z0;
+    const bool hasBad = te.hasBad != 0;
+    const T fillT = static_cast<T>(te.fillOut);  // ScaleValue's newFill_ (include/fimex/Utils.h:456)
+    const uint32_t outBytes = a.nOut * EB;
+    const char* inBase = reinterpret_cast<const char*>(a.in);
+    char* outBase = reinterpret_cast<char*>(a.out);
+    const uint32_t outRecords = (kTuningBuild && (a.flags & 2)) ? 0u : outBytes;
+    const uint32_t inRecords = (kTuningBuild && (a.flags & 1)) ? 0u : a.inBytes;
+
+    // staging list: chunk c = threadIdx.x + j * NT of the tile (byte offset of its 16 bytes inside a source slice)
+    const uint32_t waveChunk = (threadIdx.x / kWave) * kWave;
+    uint32_t gOff[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const uint32_t c = threadIdx.x + j * NT;
+        gOff[j] = (c < T_.nChunks) ? a.chunkOff[T_.chunkBase + c] * EB : 0xFFFFFFFFu;
+    }
+    const uint32_t un = (T_.nChunks + NT - 1) / NT;
+    const uint32_t slotFloats = a.slotChunks * 4u;
+    float* const spare = smem + DEPTH * slotFloats;
+    auto dma_dst = [&](uint32_t sl, int j) {
+        const uint32_t c = waveChunk + (uint32_t)j * NT;
+        return c < a.slotChunks ? smem + sl * slotFloats + c * 4u : spare;
+    };
+    for (uint32_t i = 0; i + 1 < (uint32_t)DEPTH && i < nzl; ++i) {
+        const rsrc_t rs = make_rsrc(inBase + (size_t)(z0 + i) * a.inBytes, inRecords);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if ((uint32_t)j < un) dma16(rs, dma_dst(i, j), gOff[j]);
+    }
+    // per-lane plan: output q = 2 * p + h is cell 2 * threadIdx.x + h + p * 2 * NT of the tile (row-major over the tile's width)
+    uint32_t cellOff[PER];       // byte offset inside a typed output slice, ~0u = not mine
+    uint32_t row[PER][STENCIL];  // byte offsets of the stencil rows in the staged image
+    uint32_t cellIdx[PER];
+    float xf[PER], yf[PER];
+    bool undef[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t e = 2u * threadIdx.x + (uint32_t)(q & 1) + (uint32_t)(q >> 1) * 2u * NT;
+        const uint32_t ly = e / T_.w, lx = e - ly * T_.w;
+        const uint32_t y = T_.y0 + ly;
+        cellOff[q] = 0xFFFFFFFFu;
+        cellIdx[q] = 0xFFFFFFFFu;
+        uint32_t pa = kInvalidPos;
+        xf[q] = yf[q] = 0.f;
+        if (ly < a.tileH && y < a.outY) {
+            const uint32_t cell = y * a.outX + T_.x0 + lx;
+            cellIdx[q] = cell;
+            cellOff[q] = cell * EB;
+            pa = a.ldsA[cell];
+            if (STENCIL == 2) { xf[q] = a.xf[cell]; yf[q] = a.yf[cell]; }
+        }
+        undef[q] = pa == kInvalidPos;
+        row[q][0] = undef[q] ? 0u : (pa & 0xFFFFu) * EB;
+        if (STENCIL == 2) row[q][STENCIL - 1] = undef[q] ? 0u : (pa >> 16) * EB;
+    }
+    if (T_.rsv[0] != 0) {
+        // gather tile (see staged_apply2): stencils straight from memory, element by element
+        uint32_t p[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            p[q] = (cellIdx[q] != 0xFFFFFFFFu) ? a.pos[cellIdx[q]] : kInvalidPos;
+            undef[q] = p[q] == kInvalidPos;
+            if (undef[q]) p[q] = 0;
+        }
+        auto uniform = [](const char* ptr) {
+            const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        };
+        for (uint32_t z = z0; z < z1; ++z) {
+            const rsrc_t rs = make_rsrc(uniform(inBase + (size_t)z * a.inBytes), inRecords);
+            const rsrc_t ro = make_rsrc(uniform(outBase + (size_t)z * outBytes), outRecords);
+            auto ld = [&](uint32_t cell) {
+                if constexpr (EB == 2) return as_float_nan((T)__builtin_amdgcn_raw_buffer_load_b16(rs, cell * 2u, 0, 0), te.bad, hasBad);
+                else return as_float_nan((T)__builtin_amdgcn_raw_buffer_load_b8(rs, cell, 0, 0), te.bad, hasBad);
+            };
+            float r[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                if constexpr (STENCIL == 1) {
+                    r[q] = ld(p[q]);
+                } else {
+                    const bool nnx = (__float_as_uint(xf[q]) >> 31) != 0, nny = (__float_as_uint(yf[q]) >> 31) != 0;
+                    const uint32_t dx = nnx ? 0u : 1u, dy = nny ? 0u : a.inX;
+                    const float s00 = ld(p[q]), s01 = ld(p[q] + dx), s10 = ld(p[q] + dy), s11 = ld(p[q] + dx + dy);
+                    const float top = (1.f - xf[q]) * s00 + xf[q] * s01;
+                    const float bot = (1.f - xf[q]) * s10 + xf[q] * s11;
+                    const float inter = (1.f - yf[q]) * top + yf[q] * bot;
+                    const float liny = (1 - yf[q]) * s00 + (yf[q] * s10);
+                    r[q] = nnx ? (nny ? s00 : liny) : (nny ? top : inter);
+                }
+                if (undef[q]) r[q] = undefined_f();
+            }
+            store_pair<T, PAIR>(ro, cellOff[0], cellOff[1], r[0], r[1], fillT);
+            store_pair<T, PAIR>(ro, cellOff[2], cellOff[3], r[2], r[3], fillT);
+        }
+        return;
+    }
+    if (T_.nChunks == 0) {  // every output of the tile is undefined
+        for (uint32_t z = z0; z < z1; ++z) {
+            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+            store_pair<T, PAIR>(ro, cellOff[0], cellOff[1], undefined_f(), undefined_f(), fillT);
+            store_pair<T, PAIR>(ro, cellOff[2], cellOff[3], undefined_f(), undefined_f(), fillT);
+        }
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr int NST = PAIR ? 2 : 4;  // store instructions a lane issues per slice
+    bool plainWave = true;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        plainWave = plainWave && !undef[q] && (STENCIL != 2 || ((__float_as_uint(xf[q]) | __float_as_uint(yf[q])) >> 31) == 0);
+    plainWave = __all(plainWave) != 0;
+    uint32_t mNnx[PER], mNny[PER], mUndef[PER];
+    uint32_t rowA[PER][STENCIL], rowS[PER][STENCIL];  // bilinear: aligned byte offset of a stencil row's pair, and its shift operand
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        mNnx[q] = (uint32_t)((int32_t)__float_as_uint(xf[q]) >> 31);
+        mNny[q] = (uint32_t)((int32_t)__float_as_uint(yf[q]) >> 31);
+        mUndef[q] = undef[q] ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int i = 0; i < STENCIL; ++i) { rowA[q][i] = row[q][i] & ~3u; rowS[q][i] = row[q][i] << 3; }
+    }
+    // no fill value: comparisons with NaN never hold, the loops need no separate test
+    const float badCmp = hasBad ? te.bad : undefined_f();
+    auto pick = [](uint32_t mask, float x, float y) { return __uint_as_float((__float_as_uint(x) & mask) | (__float_as_uint(y) & ~mask)); };
+    auto run = [&](auto unTag, auto plainTag) __attribute__((always_inline)) {
+        constexpr int UN = decltype(unTag)::value;
+        constexpr bool PLAIN = decltype(plainTag)::value;
+        uint32_t slot = 0;
+        for (uint32_t i = 0; i < nzl; ++i) {
+            const uint32_t z = z0 + i;
+            const bool more = i + DEPTH - 1 < nzl;
+            if (more) {
+                const uint32_t sl = (slot + DEPTH - 1 >= (uint32_t)DEPTH) ? slot - 1 : slot + DEPTH - 1;
+                const rsrc_t rs = make_rsrc(inBase + (size_t)(z + DEPTH - 1) * a.inBytes, inRecords);
+#pragma unroll
+                for (int j = 0; j < UN; ++j) dma16(rs, dma_dst(sl, j), gOff[j]);
+            }
+            const char* curb = reinterpret_cast<const char*>(smem + slot * slotFloats);
+            const rsrc_t ro = make_rsrc(outBase + (size_t)z * outBytes, outRecords);
+            float r[PER];
+            if constexpr (STENCIL == 1) {
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const float v = lds_one<T>(curb, row[q][0], te.bad, hasBad);
+                    r[q] = PLAIN ? v : pick(mUndef[q], undefined_f(), v);
+                }
+            } else {
+                float s00[PER], s01[PER], s10[PER], s11[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    if constexpr (PLAIN) {
+                        lds_pair2_raw<T>(curb, rowA[q][0], rowS[q][0], s00[q], s01[q]);
+                        lds_pair2_raw<T>(curb, rowA[q][STENCIL - 1], rowS[q][STENCIL - 1], s10[q], s11[q]);
+                    } else {
+                        lds_pair2<T>(curb, rowA[q][0], rowS[q][0], te.bad, hasBad, s00[q], s01[q]);
+                        lds_pair2<T>(curb, rowA[q][STENCIL - 1], rowS[q][STENCIL - 1], te.bad, hasBad, s10[q], s11[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const float top = (1.f - xf[q]) * s00[q] + xf[q] * s01[q];
+                    const float bot = (1.f - xf[q]) * s10[q] + xf[q] * s11[q];
+                    const float inter = (1.f - yf[q]) * top + yf[q] * bot;
+                    r[q] = inter;
+                    if constexpr (PLAIN) {  // interior cell: undefined iff one of the four is the fill value (mifi_bad2nanf, then NaN spreads)
+                        const bool anyBad = (s00[q] == badCmp) | (s01[q] == badCmp) | (s10[q] == badCmp) | (s11[q] == badCmp);
+                        r[q] = anyBad ? undefined_f() : inter;
+                    }
+                    if constexpr (!PLAIN) {
+                        const float liny = (1 - yf[q]) * s00[q] + (yf[q] * s10[q]);
+                        r[q] = pick(mNnx[q], pick(mNny[q], s00[q], liny), pick(mNny[q], top, inter));
+                        r[q] = pick(mUndef[q], undefined_f(), r[q]);
+                    }
+                }
+            }
+            store_pair<T, PAIR>(ro, cellOff[0], cellOff[1], r[0], r[1], fillT);
+            store_pair<T, PAIR>(ro, cellOff[2], cellOff[3], r[2], r[3], fillT);
+            if (more) wait_vmcnt<(DEPTH - 2) * UN + (DEPTH - 1) * NST>();
+            else wait_vmcnt<NST>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            slot = (slot + 1 == (uint32_t)DEPTH) ? 0 : slot + 1;
+        }
+    };
+    auto run_un = [&](auto unTag) __attribute__((always_inline)) {
+        if (plainWave) run(unTag, std::true_type());
+        else run(unTag, std::false_type());
+    };
+    switch (un) {
+    case 1: run_un(std::integral_constant<int, 1>()); break;
+    case 2: run_un(std::integral_constant<int, KMAX >= 2 ? 2 : 1>()); break;
+    case 3: run_un(std::integral_constant<int, KMAX >= 3 ? 3 : 1>()); break;
+    case 4: run_un(std::integral_constant<int, KMAX >= 4 ? 4 : 1>()); break;
+    case 5: run_un(std::integral_constant<int, KMAX >= 5 ? 5 : 1>()); break;
+    default: run_un(std::integral_constant<int, KMAX >= 6 ? 6 : 1>()); break;
+    }
+}
+
 constexpr uint32_t kSpareBytes = 1024;  // one wave instruction of LDS-DMA behind the ring (see staged_apply2)
 
 // chunks of one slot: the workgroup's LDS less the spare KiB, in `depth` equal slots of whole wave instructions
@@ -497,14 +833,15 @@ void launch_shape(const Staged2Plan& s, const Staged2Args& a, dim3 grid, hipStre
 }
 
 template <int STENCIL>
-bool build_shape(fimex_amd_regrid_plan& plan, Staged2Plan& s, const double* d_px, const double* d_py, hipStream_t stream, const Shape2& sh, uint32_t stripe)
+bool build_shape(const fimex_amd_regrid_plan& plan, Staged2Plan& s, const NeedSource& need, hipStream_t stream, const Shape2& sh, uint32_t stripe,
+                 uint32_t cpc = 4)
 {
     const uint32_t outX = (uint32_t)plan.outX, outY = (uint32_t)plan.outY;
     const uint32_t tileH = sh.tileH;
     const uint32_t nBands = (uint32_t)ceil_div(outY, tileH);
     // the ring holds `depth` slots, each large enough for any tile (chunks rounded up to whole wave instructions)
     uint32_t cap = std::min<uint32_t>(slot_chunks(sh.ldsBytes, sh.depth), (uint32_t)sh.kmax * sh.nt);
-    cap = std::min<uint32_t>(cap, 16383u);  // 16-bit LDS offsets in floats
+    cap = std::min<uint32_t>(cap, 65535u / cpc);  // 16-bit LDS offsets, in elements
     const uint32_t step = sh.tileW >= 128 ? 64u : 32u;  // tile widths are multiples of this (a wave stores 64 consecutive cells)
     // Tiles: every tile row starts as tiles of the widest shape.  A tile that does not fit (too many chunks for a slot, too
     // many source rows) makes its row narrower when most tiles of the row fail (the row's cells cover more source: rows near
@@ -534,8 +871,8 @@ bool build_shape(fimex_amd_regrid_plan& plan, Staged2Plan& s, const double* d_px
         if (tiles.size() > 0x7FFFFFFFu / 8) return false;
         dTiles.allocate(tiles.size());
         FA_HIP(hipMemcpyAsync(dTiles.get(), tiles.data(), tiles.size() * sizeof(StagedTile), hipMemcpyHostToDevice, stream));
-        tile_scan<STENCIL><<<(uint32_t)tiles.size(), kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, outX, outY, tileH,
-                                                                       dTiles.get(), cap, 0, nullptr, nullptr, nullptr);
+        tile_scan<STENCIL><<<(uint32_t)tiles.size(), kBlock, 0, stream>>>(need, (int64_t)plan.inX, (int64_t)plan.inY, outX, outY, tileH,
+                                                                       dTiles.get(), cap, 0, nullptr, nullptr, nullptr, cpc);
         FA_HIP(hipGetLastError());
         FA_HIP(hipMemcpyAsync(tiles.data(), dTiles.get(), tiles.size() * sizeof(StagedTile), hipMemcpyDeviceToHost, stream));
         FA_HIP(hipStreamSynchronize(stream));
@@ -598,8 +935,8 @@ bool build_shape(fimex_amd_regrid_plan& plan, Staged2Plan& s, const double* d_px
     s.chunkOff.allocate(std::max<size_t>(total, 1));
     s.ldsA.allocate(n);
     s.ldsB.allocate(STENCIL == 4 ? n : 0);
-    tile_scan<STENCIL><<<(uint32_t)tiles.size(), kBlock, 0, stream>>>(d_px, d_py, (int64_t)plan.inX, (int64_t)plan.inY, outX, outY, tileH,
-                                                                   dTiles.get(), cap, 1, s.chunkOff.get(), s.ldsA.get(), s.ldsB.get());
+    tile_scan<STENCIL><<<(uint32_t)tiles.size(), kBlock, 0, stream>>>(need, (int64_t)plan.inX, (int64_t)plan.inY, outX, outY, tileH,
+                                                                   dTiles.get(), cap, 1, s.chunkOff.get(), s.ldsA.get(), s.ldsB.get(), cpc);
     FA_HIP(hipGetLastError());
     // workgroup -> tile: workgroups are dealt round-robin over the XCDs (b % 8 shares an L2); tile rows go to the XCDs in
     // stripes of `stripe` rows, so that neighbours in x (and, inside a stripe, in y) run on the same XCD and meet in its L2
@@ -630,7 +967,7 @@ bool build_shape(fimex_amd_regrid_plan& plan, Staged2Plan& s, const double* d_px
     s.ldsBytes = sh.ldsBytes;
     s.depth = sh.depth;
     s.totalChunks = total;
-    s.stagedCells = total * 4;
+    s.stagedCells = total * cpc;
     s.valid = true;
     return true;
 }
@@ -672,10 +1009,13 @@ bool build_staged2_shape(fimex_amd_regrid_plan& plan, Staged2Plan& target, int n
     // neighbouring tile rows at any time.  (With the chunk-major order stripes of 8 rows per XCD fetched 10.2 instead of 11.1 GB for
     // the bilinear launch at the same time; with the tile-major order stripes of 2, 4 or 8 rows lose 3-6 %.)
     const uint32_t stripe = (uint32_t)std::max(1, tuning("STAGE2_STRIPE", 1));
+    NeedSource need;
+    need.px = d_px;
+    need.py = d_py;
     switch (plan.kind) {
-    case PlanKind::Nearest: return build_shape<1>(plan, target, d_px, d_py, stream, sh, stripe);
-    case PlanKind::Bilinear: return build_shape<2>(plan, target, d_px, d_py, stream, sh, stripe);
-    case PlanKind::Bicubic: return build_shape<4>(plan, target, d_px, d_py, stream, sh, stripe);
+    case PlanKind::Nearest: return build_shape<1>(plan, target, need, stream, sh, stripe);
+    case PlanKind::Bilinear: return build_shape<2>(plan, target, need, stream, sh, stripe);
+    case PlanKind::Bicubic: return build_shape<4>(plan, target, need, stream, sh, stripe);
     default: return false;
     }
 }
@@ -765,6 +1105,140 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
         break;
     }
     FA_HIP(hipGetLastError());
+}
+
+// ---- stored types
+namespace {
+
+// the plan's staged form for slices of elemBytes-byte elements (2 or 1), built on first use; nullptr: none (the caller takes
+// the first staged form or the gather kernels)
+const Staged2Plan* staged2_typed_form(const fimex_amd_regrid_plan& plan, uint32_t elemBytes, hipStream_t stream)
+{
+    if (plan.kind != PlanKind::Nearest && plan.kind != PlanKind::Bilinear) return nullptr;
+    if ((plan.inX * plan.inY * elemBytes) % 4 != 0) return nullptr;  // slices start on 4-byte boundaries (LDS-DMA)
+    const int idx = elemBytes == 2 ? 0 : 1;
+    std::lock_guard<std::mutex> lock(plan.typed2.mtx);
+    Staged2Plan& form = plan.typed2.form[idx];
+    if (!plan.typed2.tried[idx]) {
+        plan.typed2.tried[idx] = true;
+        // 512 threads on 256 x 8 tiles, two workgroups per CU: the kernel converts every element it touches and is bound by its
+        // instructions as much as by memory, so occupancy counts for more than tile size here
+        Shape2 sh{};
+        sh.nt = tuning("STAGE2T_NT", 512);
+        if (!(sh.nt == 256 || sh.nt == 512 || sh.nt == 1024)) return nullptr;
+        sh.per = 4;
+        sh.kmax = sh.nt == 1024 ? 5 : 6;
+        sh.tileW = (uint32_t)tuning("STAGE2T_TW", sh.nt / 2);
+        const uint32_t outputs = (uint32_t)sh.nt * 4u;
+        if (sh.tileW < 64 || sh.tileW % 64 != 0 || outputs % sh.tileW != 0) return nullptr;
+        sh.tileH = outputs / sh.tileW;
+        sh.ldsBytes = (uint32_t)tuning("STAGE2T_LDS_KB", sh.nt == 256 ? 39 : (sh.nt == 512 ? 79 : 159)) * 1024u;
+        if (sh.ldsBytes > 160u * 1024u - 64u) sh.ldsBytes = 160u * 1024u - 64u;
+        if (sh.ldsBytes < 16u * 1024u) return nullptr;
+        sh.depth = (sh.nt == 512 && tuning("STAGE2T_DEPTH", 2) == 3) ? 3u : 2u;
+        NeedSource need;
+        need.pos = plan.pos.get();
+        need.xf = plan.xf.get();
+        need.yf = plan.yf.get();
+        const uint32_t cpc = 16u / elemBytes;
+        try {
+            if (plan.kind == PlanKind::Nearest) build_shape<1>(plan, form, need, stream, sh, 1, cpc);
+            else build_shape<2>(plan, form, need, stream, sh, 1, cpc);
+        } catch (...) {
+            form.valid = false;
+            throw;
+        }
+    }
+    return form.valid ? &form : nullptr;
+}
+
+template <int STENCIL, typename T>
+void launch_typed_shape(const Staged2Plan& s, const Staged2Args& a, const TypedEdge& te, dim3 grid, hipStream_t stream)
+{
+    auto go = [&](auto kernel, int nt) {
+        allow_dynamic_lds(reinterpret_cast<const void*>(kernel), s.ldsBytes);
+        kernel<<<grid, nt, s.ldsBytes, stream>>>(a, te);
+    };
+    const bool pair = te.pairStore != 0;
+    if (s.nt == 512 && s.depth == 3) {
+        pair ? go(&staged_apply2_typed<STENCIL, 512, 6, T, true, 3>, 512) : go(&staged_apply2_typed<STENCIL, 512, 6, T, false, 3>, 512);
+        return;
+    }
+    switch (s.nt) {
+    case 256: pair ? go(&staged_apply2_typed<STENCIL, 256, 6, T, true>, 256) : go(&staged_apply2_typed<STENCIL, 256, 6, T, false>, 256); break;
+    case 512: pair ? go(&staged_apply2_typed<STENCIL, 512, 6, T, true>, 512) : go(&staged_apply2_typed<STENCIL, 512, 6, T, false>, 512); break;
+    case 1024: pair ? go(&staged_apply2_typed<STENCIL, 1024, 5, T, true>, 1024) : go(&staged_apply2_typed<STENCIL, 1024, 5, T, false>, 1024); break;
+    default: throw Error("staged2 typed: unexpected workgroup shape");
+    }
+}
+
+template <typename T>
+void launch_typed_t(const fimex_amd_regrid_plan& plan, const Staged2Plan& s, const Staged2Args& a, const TypedEdge& te, dim3 grid, hipStream_t stream)
+{
+    if (plan.kind == PlanKind::Nearest) launch_typed_shape<1, T>(s, a, te, grid, stream);
+    else launch_typed_shape<2, T>(s, a, te, grid, stream);
+}
+
+}  // namespace
+
+// data2InterpolationArray + interpolateValues + interpolationArray2Data (src/CDMInterpolator.cc:115-124, 251-285) on slices of
+// 1- and 2-byte integers, nearest and bilinear, through the second staged form.  false: not applicable, the caller goes on.
+bool launch_staged2_apply_typed(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                                hipStream_t stream)
+{
+    if (!(cdmType == FIMEX_AMD_CDM_CHAR || cdmType == FIMEX_AMD_CDM_UCHAR || cdmType == FIMEX_AMD_CDM_SHORT || cdmType == FIMEX_AMD_CDM_USHORT))
+        return false;
+    const uint32_t eb = (cdmType == FIMEX_AMD_CDM_SHORT || cdmType == FIMEX_AMD_CDM_USHORT) ? 2u : 1u;
+    if (reinterpret_cast<uintptr_t>(d_in) % 4 != 0) return false;
+    if (nz == 0) return true;
+    const Staged2Plan* form = staged2_typed_form(plan, eb, stream);
+    if (!form) return false;
+    const Staged2Plan& s = *form;
+    Staged2Args a{};
+    a.in = static_cast<const float*>(d_in);
+    a.out = static_cast<float*>(d_out);
+    a.tiles = s.tiles.get();
+    a.order = s.order.get();
+    a.chunkOff = s.chunkOff.get();
+    a.ldsA = s.ldsA.get();
+    a.ldsB = s.ldsB.get();
+    a.pos = plan.pos.get();
+    a.inX = (uint32_t)plan.inX;
+    a.xf = plan.xf.get();
+    a.yf = plan.yf.get();
+    a.outX = (uint32_t)plan.outX;
+    a.outY = (uint32_t)plan.outY;
+    a.tileH = s.tileH;
+    a.inBytes = (uint32_t)(plan.inX * plan.inY * eb);
+    a.nOut = (uint32_t)(plan.outX * plan.outY);
+    a.nz = (uint32_t)nz;
+    uint32_t zpb = (uint32_t)tuning("STAGE2T_ZPB", 25);
+    if (zpb < 1) zpb = 1;
+    if (ceil_div(nz, (size_t)zpb) > 16) zpb = (uint32_t)ceil_div(nz, (size_t)16);
+    const uint32_t n = (uint32_t)ceil_div(nz, (size_t)zpb);
+    for (uint32_t c = 0, z = 0; c < n; ++c) {
+        a.zStart[c] = z;
+        z += (uint32_t)nz / n + (c < (uint32_t)nz % n ? 1u : 0u);
+    }
+    a.zStart[n] = (uint32_t)nz;
+    a.nZChunks = n;
+    a.slotChunks = slot_chunks(s.ldsBytes, s.depth);
+    a.flags = (uint32_t)tuning("STAGE2_ABLATE", 0);
+    TypedEdge te{};
+    te.bad = (float)badValue;
+    te.hasBad = !(te.bad != te.bad);
+    te.fillOut = badValue;
+    // two results per store where both the row length and the slice start allow aligned 4-byte (2-byte) stores
+    te.pairStore = (plan.outX % 2 == 0 && reinterpret_cast<uintptr_t>(d_out) % 4 == 0 && tuning("STAGE2T_PAIR", 1) != 0) ? 1u : 0u;
+    const dim3 grid(s.gridX * n, 1, 1);
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: launch_typed_t<signed char>(plan, s, a, te, grid, stream); break;
+    case FIMEX_AMD_CDM_UCHAR: launch_typed_t<unsigned char>(plan, s, a, te, grid, stream); break;
+    case FIMEX_AMD_CDM_SHORT: launch_typed_t<short>(plan, s, a, te, grid, stream); break;
+    default: launch_typed_t<unsigned short>(plan, s, a, te, grid, stream); break;
+    }
+    FA_HIP(hipGetLastError());
+    return true;
 }
 
 }  // namespace fimex_amd

@@ -7,14 +7,21 @@ import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(cmd):
+ABNORMAL = []
+
+
+def run(cmd, note_file=None):
     print("run:", " ".join(cmd[:8]), "...", flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", timeout=280)
     if r.returncode != 0:
-        # rocprofv3 has been seen to crash in its exit handlers after a run that launched a cooperative kernel (the fills on
-        # small batches): the program's result line and the profiler's files are complete by then
-        if '"case"' in r.stdout:
-            print("note: profiled run ended with status %d after its result line; files kept" % r.returncode, flush=True)
+        # A profiled run that ends abnormally AFTER its result line (seen with the cooperative launches of the small-batch fills)
+        # is not passed over: its status and the end of its stderr are written next to the profile, listed at the end of this
+        # script's output, and the script itself exits non-zero.  The profile files are kept for reading.
+        if '"case"' in r.stdout and note_file:
+            with open(note_file, "a") as f:
+                f.write("command: %s\nstatus: %d\n--- stdout (end)\n%s\n--- stderr (end)\n%s\n\n" % (" ".join(cmd), r.returncode, r.stdout[-1500:], r.stderr[-6000:]))
+            ABNORMAL.append((cmd[3] if len(cmd) > 3 else "", r.returncode, note_file))
+            print("ABNORMAL EXIT: status %d after the result line; see %s" % (r.returncode, note_file), flush=True)
             return r
         print(r.stdout[-2000:], r.stderr[-2000:], flush=True)
         sys.exit(1)
@@ -30,7 +37,8 @@ def main():
     for case in cases:
         work = "/tmp/prof_%s_%s" % (tag, case)
         shutil.rmtree(work, ignore_errors=True)
-        r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", work + "/trace", "--"] + prog + [case])
+        note = os.path.join(out, "%s_%s_abnormal_exit.txt" % (tag, case))
+        r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", work + "/trace", "--"] + prog + [case], note)
         runrec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"case"')][-1])
         json.dump(runrec, open(os.path.join(out, "%s_%s_run.json" % (tag, case)), "w"), indent=1)
         ks = glob.glob(work + "/trace/**/*_kernel_stats.csv", recursive=True)[0]
@@ -39,7 +47,7 @@ def main():
         pmc = {"case": case, "calls_profiled": calls}
         for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
             d = work + "/pmc_" + cnt
-            run(["rocprofv3", "--kernel-trace", "--pmc", cnt, "--output-format", "csv", "-d", d, "--"] + prog + [case])
+            run(["rocprofv3", "--kernel-trace", "--pmc", cnt, "--output-format", "csv", "-d", d, "--"] + prog + [case], note)
             f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
             per = collections.defaultdict(float)
             for x in csv.DictReader(open(f)):
@@ -58,6 +66,9 @@ def main():
         json.dump(pmc, open(os.path.join(out, "%s_%s_pmc.json" % (tag, case)), "w"), indent=1)
         print(json.dumps(runrec)[:600], flush=True)
         print(json.dumps(pmc)[:900], flush=True)
+    if ABNORMAL:
+        print("abnormal exits of profiled runs:", ABNORMAL, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

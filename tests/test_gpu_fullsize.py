@@ -285,3 +285,32 @@ def test_bench_launcher_with_two_ranks_on_one_device():
     assert d["verified_slices"] == [0, 1, 3] and d["verified_all_slices_vs_gather"] is True  # rank 0's block; a failure on any rank exits 1
     assert d["gather"]["write_back_verified"] is True
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("method", [oracle.BILINEAR, oracle.NEAREST])
+@pytest.mark.parametrize("dt", [np.int16, np.uint8])
+def test_c2_stored_types_full_grid(fa, c2, method, dt):
+    """configs[1] geometry on a variable's stored type (packed shorts, bytes): fimex_amd_regrid_apply_typed_device -- one kernel that
+    reads and writes the stored type through the second staged form -- against the oracle's three steps (data2InterpolationArray,
+    interpolateValues, interpolationArray2Data; src/CDMInterpolator.cc:115-124, 251-285) on the whole 2000 x 2000 grid, 7 slices;
+    with and without fill values in the data, and an odd slice count below and above the staging threshold."""
+    import torch
+    wl, px, py, f = c2
+    info = np.iinfo(dt)
+    bad = float(info.min)
+    rng = np.random.default_rng(5)
+    code = oracle.cdm_type_of(dt)
+    plan = fa.RegridPlan(method, px, py, wl.inX, wl.inY, wl.outX, wl.outY)
+    for nz, holes in ((7, True), (3, True), (5, False)):
+        scale = (info.max - 3) / 40.0
+        g = np.clip(np.round((np.nan_to_num(f[:1], nan=280.0) - 280.0) * scale / 4 + rng.integers(-3, 4, (nz, wl.inY, wl.inX))), info.min + 1, info.max).astype(dt)
+        if holes:
+            g.reshape(-1)[rng.choice(g.size, g.size // 500, replace=False)] = dt(bad)
+        want = oracle.interpolation_array2data(
+            oracle.interpolate_values(method, px, py, oracle.data2interpolation_array(g, bad), wl.inX, wl.inY, wl.outX, wl.outY, nthreads=16), code, bad)
+        t = torch.from_numpy(g.view(np.uint8)).cuda()
+        out = torch.zeros(want.nbytes, dtype=torch.uint8, device="cuda")
+        fa.regrid_apply_typed_device(plan, t.data_ptr(), code, nz, bad, out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(dt).reshape(want.shape)
+        assert np.array_equal(got, want), (np.dtype(dt).name, method, nz, int((got != want).sum()))

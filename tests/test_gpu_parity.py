@@ -854,9 +854,11 @@ def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, 
     results = []
     # TYPED_STAGED 1: 1- and 2-byte types through the LDS-staged kernels; 0: the gather kernels on the stored type
     # TYPED_FUSED 2: also bicubic through the stored-type gather kernel; 0: three passes
-    for staged, fused in (("1", "1"), ("0", "2"), ("0", "1"), ("0", "0")):
+    # TYPED_STAGED2 1: the second staged form (staged2.hip, nearest and bilinear) before the first
+    for staged, fused, second in (("1", "1", "1"), ("1", "1", "0"), ("0", "2", "1"), ("0", "1", "1"), ("0", "0", "1")):
         monkeypatch.setenv("FIMEX_AMD_TYPED_STAGED", staged)
         monkeypatch.setenv("FIMEX_AMD_TYPED_FUSED", fused)
+        monkeypatch.setenv("FIMEX_AMD_TYPED_STAGED2", second)
         out = torch.zeros(nz * outY * outX * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
         fa.regrid_apply_typed_device(plan, t.data_ptr(), code, nz, bad, out.data_ptr())
         torch.cuda.synchronize()

@@ -907,8 +907,18 @@ struct MultiWg {
     unsigned int* error;      // one word per launch
     unsigned long long* prof = nullptr;  // tuning build, experiment 4: cycles summed over bands: [0] events, [1] steps, [2] bands
 };
-constexpr unsigned int kSpinCapLds = 1u << 24;     // ~1 s of polling LDS
-constexpr unsigned int kSpinCapGlobal = 1u << 21;  // ~1 s of polling memory
+// A wait gives up after kSpinCapTicks of WALL time (s_memrealtime, the 100 MHz constant clock): long enough that workgroups
+// kept off their CUs by other work on the device -- a concurrent one-workgroup-per-slice fill of a long batch, another process --
+// still arrive (they are queued behind that work, not lost), short enough that a wrong counter ends the call instead of hanging
+// the GPU.  The clock is read only every 4096th (256th) poll, for the first time after that many polls: a wait that ends
+// quickly never reads it.
+constexpr unsigned long long kSpinCapTicks = 30ull * 100000000ull;  // 30 s
+__device__ __forceinline__ bool spin_expired(unsigned long long& t0)
+{
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) { t0 = now | 1ull; return false; }
+    return now - t0 > kSpinCapTicks;
+}
 
 __device__ __forceinline__ bool launch_failed(const unsigned int* error)
 {
@@ -921,19 +931,21 @@ __device__ __forceinline__ void fail_launch(unsigned int* error, unsigned int co
 // waits until the LDS word reaches `need`; false: gave up (cap or another wave's failure)
 __device__ __forceinline__ bool wait_lds_at_least(const unsigned int* flag, unsigned int need, unsigned int* error)
 {
+    unsigned long long t0 = 0;
     for (unsigned int it = 0;; ++it) {
         asm volatile("" ::: "memory");
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) { asm volatile("" ::: "memory"); return true; }
         __builtin_amdgcn_s_sleep(1);
-        if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(error))) { fail_launch(error, 1); return false; }
+        if ((it & 0xFFF) == 0xFFF && (spin_expired(t0) || launch_failed(error))) { fail_launch(error, 1); return false; }
     }
 }
 __device__ __forceinline__ bool wait_global_at_least(const unsigned int* flag, unsigned int need, unsigned int* error)
 {
+    unsigned long long t0 = 0;
     for (unsigned int it = 0;; ++it) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { asm volatile("" ::: "memory"); return true; }
         __builtin_amdgcn_s_sleep(2);
-        if ((it & 0xFF) == 0xFF && (it >= kSpinCapGlobal || launch_failed(error))) { fail_launch(error, 2); return false; }
+        if ((it & 0xFF) == 0xFF && (spin_expired(t0) || launch_failed(error))) { fail_launch(error, 2); return false; }
     }
 }
 // barrier of the G workgroups of one slice on a monotone global counter (instance k waits for k * G arrivals)
@@ -1204,11 +1216,12 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 if (hasBelow) {
                     const unsigned int limit = xpc + kCh - L;  // columns < limit are written during this chunk
                     const unsigned long long t0 = prof ? clock64() : 0;
+                    unsigned long long tSpin = 0;
                     for (unsigned int it = 0;; ++it) {
                         const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
                         if (limit <= (cns & 0x7FFFFu) + kHandW) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(mg.error))) { fail_launch(mg.error, 3); break; }
+                        if ((it & 0xFFF) == 0xFFF && (spin_expired(tSpin) || launch_failed(mg.error))) { fail_launch(mg.error, 3); break; }
                     }
                     if (prof) tFlush += clock64() - t0;  // (window waits, counted apart)
                 }
@@ -1886,11 +1899,12 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                     lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
                 if (hasBelow) {
                     const unsigned int limit = xpc + kCreepCh - L;
+                    unsigned long long tSpin = 0;
                     for (unsigned int it = 0;; ++it) {
                         const unsigned int cns = lds_observe(&hand.consumed[slotOut]);
                         if (limit <= (cns & 0x7FFFFu) + kHandWC) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if ((it & 0xFFF) == 0xFFF && (it >= kSpinCapLds || launch_failed(error))) { fail_launch(error, 3); break; }
+                        if ((it & 0xFFF) == 0xFFF && (spin_expired(tSpin) || launch_failed(error))) { fail_launch(error, 3); break; }
                     }
                 }
             }

@@ -757,8 +757,11 @@ __global__ void __launch_bounds__(NT) staged_apply2_typed(Staged2Args a, TypedEd
                     const float inter = (1.f - yf[q]) * top + yf[q] * bot;
                     r[q] = inter;
                     if constexpr (PLAIN) {  // interior cell: undefined iff one of the four is the fill value (mifi_bad2nanf, then NaN spreads)
-                        const bool anyBad = (s00[q] == badCmp) | (s01[q] == badCmp) | (s10[q] == badCmp) | (s11[q] == badCmp);
-                        r[q] = anyBad ? undefined_f() : inter;
+                        // (the stored elements are integers, exact in float, and so is a fill value that can occur among them: the
+                        // product of the four differences is zero iff one element is the fill value -- one comparison and one
+                        // selection per output instead of four of each; without a fill value the product is NaN and never zero)
+                        const float anyBad = ((s00[q] - badCmp) * (s01[q] - badCmp)) * ((s10[q] - badCmp) * (s11[q] - badCmp));
+                        r[q] = (anyBad == 0.f) ? undefined_f() : inter;
                     }
                     if constexpr (!PLAIN) {
                         const float liny = (1 - yf[q]) * s00[q] + (yf[q] * s10[q]);
@@ -1212,10 +1215,14 @@ bool launch_staged2_apply_typed(const fimex_amd_regrid_plan& plan, const void* d
     a.inBytes = (uint32_t)(plan.inX * plan.inY * eb);
     a.nOut = (uint32_t)(plan.outX * plan.outY);
     a.nz = (uint32_t)nz;
-    uint32_t zpb = (uint32_t)tuning("STAGE2T_ZPB", 25);
+    // z chunks of about 50 slices (200 slices: 1.354 against 1.364 ms with 25, profiles/r03_sweep_typed*.log), at least four
+    // where the batch allows, so that short batches still fill the chip
+    uint32_t zpb = (uint32_t)tuning("STAGE2T_ZPB", 50);
     if (zpb < 1) zpb = 1;
     if (ceil_div(nz, (size_t)zpb) > 16) zpb = (uint32_t)ceil_div(nz, (size_t)16);
-    const uint32_t n = (uint32_t)ceil_div(nz, (size_t)zpb);
+    uint32_t n = (uint32_t)ceil_div(nz, (size_t)zpb);
+    n = std::max<uint32_t>(n, (uint32_t)std::min<size_t>(4, nz / 6));
+    if (n < 1) n = 1;
     for (uint32_t c = 0, z = 0; c < n; ++c) {
         a.zStart[c] = z;
         z += (uint32_t)nz / n + (c < (uint32_t)nz % n ? 1u : 0u);

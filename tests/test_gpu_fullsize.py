@@ -314,3 +314,49 @@ def test_c2_stored_types_full_grid(fa, c2, method, dt):
         torch.cuda.synchronize()
         got = out.cpu().numpy().view(dt).reshape(want.shape)
         assert np.array_equal(got, want), (np.dtype(dt).name, method, nz, int((got != want).sum()))
+
+
+def test_small_batch_fills_on_a_busy_device(fa):
+    """The fills of small batches run several workgroups per slice that wait for each other (cooperative launch).  While a long
+    one-workgroup-per-slice fill of another batch holds most CUs, some of those workgroups are queued behind it for seconds: the
+    waits inside the kernels are bounded in WALL time (30 s), not in polls, so the call neither fails nor changes its result.
+    A second stream from a second thread runs the long fill; the small batch is filled meanwhile and compared with the same fill
+    on the idle device and, for one slice, with the oracle."""
+    import threading
+    import torch
+    nyS, nxS, nzS = 1500, 1500, 8
+    small = cases.holes(nzS, nyS, nxS, seed=31, frac=0.2)
+    d_ref = torch.from_numpy(small).cuda()
+    fa.fill2d_device(d_ref.data_ptr(), nxS, nyS, nzS, 1e-9, 1.6, 100, torch.cuda.current_stream().cuda_stream)
+    ref = d_ref.cpu().numpy()
+    want0, _ = oracle.fill2d(small[0], 1e-9, 1.6, 100)
+    assert cases.same(ref[0], want0), cases.describe_mismatch(ref[0], want0)
+    # the long one: 220 slices of 2000 x 2000, ten times the sweeps
+    big = torch.from_numpy(cases.holes(4, 2000, 2000, seed=32)).cuda().repeat(55, 1, 1).contiguous()
+    side = torch.cuda.Stream()
+    errors = []
+
+    def long_fill():
+        try:
+            torch.cuda.set_device(0)
+            fa.set_device(0)
+            fa.fill2d_device(big.data_ptr(), 2000, 2000, 220, 1e-12, 1.6, 1000, side.cuda_stream)
+        except Exception as e:  # reported by the main thread
+            errors.append(e)
+
+    t = threading.Thread(target=long_fill)
+    t.start()
+    import time
+    time.sleep(0.5)
+    busy_results = []
+    for rep in range(2):
+        d = torch.from_numpy(small).cuda()
+        fa.fill2d_device(d.data_ptr(), nxS, nyS, nzS, 1e-9, 1.6, 100, torch.cuda.current_stream().cuda_stream)
+        busy_results.append((t.is_alive(), d.cpu().numpy()))
+        d2 = torch.from_numpy(small).cuda()
+        fa.creepfill2d_device(d2.data_ptr(), nxS, nyS, nzS, 20, 2, torch.cuda.current_stream().cuda_stream)
+    t.join()
+    assert not errors, errors
+    for alive, got in busy_results:
+        assert cases.same(got, ref)
+    assert busy_results[0][0], "the long fill had ended before the small one ran: the test did not exercise the busy device"

@@ -56,6 +56,7 @@ struct FwdArgs {
     size_t inLayer;
     uint32_t nz;
     uint32_t zPerBlock;
+    uint32_t rankAll;  // tuning build (FWD_MEDIAN_SHORT=0): the median of every bucket by rank counting
 };
 
 template <bool UNDEF>
@@ -96,11 +97,43 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
         if (cnt[k] != 0) {
             if (KIND == 1) r[k] = acc[k] / (float)cnt[k];  // aggrMean: sum / size()
             else if (KIND == 5) {
-                // a NaN inside an "undef" bucket: see forward_apply_median
+                // a NaN inside an "undef" bucket: see median_by_rank
                 if (!(UNDEF && anyNan[k])) r[k] = (cnt[k] == 1 || acc[k] > second[k]) ? acc[k] : second[k];
             } else r[k] = acc[k];
         }
     }
+}
+
+// value of rank size()/2 among the kept values of one bucket of one slice (std::nth_element, src/CachedForwardInterpolation.cc:49-53)
+template <bool UNDEF>
+__device__ __forceinline__ float median_by_rank(const FwdArgs& a, uint32_t b, uint32_t e, const float* src)
+{
+    uint32_t n = 0;
+    bool anyNan = false;
+    for (uint32_t j = b; j < e; ++j) {
+        const float v = src[a.src[j]];
+        if (isnan(v)) anyNan = true;
+        if (keep<UNDEF>(v)) n++;
+    }
+    float r = undefined_f();
+    // a NaN inside an "undef" bucket: the reference's nth_element result is implementation-defined
+    // (comparator not a strict weak order); the documented intent (value + undef = undef) is kept
+    if (n != 0 && !(UNDEF && anyNan)) {
+        const uint32_t want = n / 2;
+        for (uint32_t j = b; j < e; ++j) {
+            const float v = src[a.src[j]];
+            if (!keep<UNDEF>(v)) continue;
+            uint32_t less = 0, equalBefore = 0;
+            for (uint32_t q = b; q < e; ++q) {
+                const float w = src[a.src[q]];
+                if (!keep<UNDEF>(w)) continue;
+                less += (w < v);
+                equalBefore += (w == v && q < j);
+            }
+            if (less + equalBefore == want) { r = v; break; }
+        }
+    }
+    return r;
 }
 
 // one lane per target cell.  Workgroups are dealt round-robin over the 8 XCDs; XCD x takes the x-th eighth of the target
@@ -117,6 +150,13 @@ __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
     const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
     const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
     const uint32_t i0 = (e > b) ? a.src[b] : 0u;
+    if (KIND == 5 && (e - b > 2 || (kTuningBuild && a.rankAll != 0))) {
+        // median of a bucket of three or more source cells: value of rank size()/2 (std::nth_element, :49-53) by rank counting, slice
+        // by slice -- no scratch memory, any bucket size; the other lanes of the wave (buckets of at most two cells, by far the
+        // most in practice: DESIGN.md gives the occupancy histogram) take the batched path below
+        for (uint32_t z = z0; z < z1; ++z) __builtin_nontemporal_store(median_by_rank<UNDEF>(a, b, e, a.in + (size_t)z * a.inLayer), a.out + (size_t)z * a.nOut + t);
+        return;
+    }
     for (uint32_t z = z0; z < z1; z += ZC) {
         const float* src = a.in + (size_t)z * a.inLayer;
         // slices past the end of the chunk re-read the last one (results dropped): no branch in the gather loop
@@ -128,47 +168,6 @@ __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 #pragma unroll
         for (int k = 0; k < ZC; ++k)
             if (z + k < z1) __builtin_nontemporal_store(r[k], a.out + (size_t)(z + k) * a.nOut + t);
-    }
-}
-
-// median: value of rank size()/2 (std::nth_element, :49-53), by rank counting -- no scratch memory,
-// any bucket size; buckets are short in practice (DESIGN.md gives the occupancy histogram)
-template <bool UNDEF>
-__global__ void __launch_bounds__(kBlock) forward_apply_median(FwdArgs a)
-{
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= a.nOut) return;
-    const uint32_t z0 = blockIdx.y * a.zPerBlock;
-    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
-    const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
-    for (uint32_t z = z0; z < z1; ++z) {
-        const float* src = a.in + (size_t)z * a.inLayer;
-        uint32_t n = 0;
-        bool anyNan = false;
-        for (uint32_t j = b; j < e; ++j) {
-            const float v = src[a.src[j]];
-            if (isnan(v)) anyNan = true;
-            if (keep<UNDEF>(v)) n++;
-        }
-        float r = undefined_f();
-        // a NaN inside an "undef" bucket: the reference's nth_element result is implementation-defined
-        // (comparator not a strict weak order); the documented intent (value + undef = undef) is kept
-        if (n != 0 && !(UNDEF && anyNan)) {
-            const uint32_t want = n / 2;
-            for (uint32_t j = b; j < e; ++j) {
-                const float v = src[a.src[j]];
-                if (!keep<UNDEF>(v)) continue;
-                uint32_t less = 0, equalBefore = 0;
-                for (uint32_t q = b; q < e; ++q) {
-                    const float w = src[a.src[q]];
-                    if (!keep<UNDEF>(w)) continue;
-                    less += (w < v);
-                    equalBefore += (w == v && q < j);
-                }
-                if (less + equalBefore == want) { r = v; break; }
-            }
-        }
-        __builtin_nontemporal_store(r, a.out + (size_t)z * a.nOut + t);
     }
 }
 
@@ -350,6 +349,7 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.nOut = (uint32_t)(plan.outX * plan.outY);
     a.inLayer = plan.inX * plan.inY;
     a.nz = (uint32_t)nz;
+    a.rankAll = tuning("FWD_MEDIAN_SHORT", 1) == 0 ? 1u : 0u;
     // z chunks: a workgroup reads its CSR entries once per chunk, so chunks are long (the CSR of configs[3] is 10 MB, a slice's
     // must-move bytes about the same); several chunks only where the target grid alone would not fill the chip
     const size_t blocks = ceil_div(a.nOut, kBlock);
@@ -375,12 +375,10 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     case Aggregate::Max: u ? launch_kind<3, true>(a, gridLane, wavePath, stream) : launch_kind<3, false>(a, gridLane, wavePath, stream); break;
     case Aggregate::Min: u ? launch_kind<4, true>(a, gridLane, wavePath, stream) : launch_kind<4, false>(a, gridLane, wavePath, stream); break;
     case Aggregate::Median:
-        if (plan.info.maxBucket <= 2 && tuning("FWD_MEDIAN_SHORT", 1) != 0) {  // no bucket holds more than two cells: four slices in flight, no rank counting
-            // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
-            if (u) forward_apply_lane<5, true, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
-            else forward_apply_lane<5, false, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
-        } else if (u) forward_apply_median<true><<<grid, kBlock, 0, stream>>>(a);
-        else forward_apply_median<false><<<grid, kBlock, 0, stream>>>(a);
+        // buckets of at most two cells: eight slices in flight, no rank counting; longer ones are ranked slice by slice by the same kernel
+        // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
+        if (u) forward_apply_lane<5, true, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
+        else forward_apply_lane<5, false, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
         break;
     }
     FA_HIP(hipGetLastError());

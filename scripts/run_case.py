@@ -16,10 +16,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("case")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--tuning-build", action="store_true", help="libfimex_amd_tuning.so: reads the FIMEX_AMD_<NAME> experiment switches")
     a = ap.parse_args()
     import torch
     from fimex_amd import capi as fa
     import workloads, bench, cases
+    if a.tuning_build:
+        fa.use_tuning_build(True)
     fa.load(); fa.set_device(0)
     st = torch.cuda.current_stream().cuda_stream
 

@@ -43,7 +43,7 @@ def main():
         json.dump(runrec, open(os.path.join(out, "%s_%s_run.json" % (tag, case)), "w"), indent=1)
         ks = glob.glob(work + "/trace/**/*_kernel_stats.csv", recursive=True)[0]
         shutil.copy(ks, os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, case)))
-        calls = runrec["reps"] + 1  # run_case.py makes one warm-up call
+        calls = runrec["reps"] + runrec.get("warm", 2)  # run_case.py makes two warm-up calls
         pmc = {"case": case, "calls_profiled": calls}
         for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
             d = work + "/pmc_" + cnt

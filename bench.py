@@ -399,6 +399,8 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "n_src_bbox": n_src_bbox, "n_src_touched": n_src_touched, "plan_bytes": info["planBytes"],
             "frac_if_only_touched_cells_counted": alg_bytes_touched / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "frac_on_staged_bytes": ((nz * 4 * (info.get("stagedCells") + out_layer) + info["planBytes"]) / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                                    if info.get("stagedCells") else None,
         },
     }
 
@@ -451,6 +453,8 @@ def main():
                                 "bounding box %.1f %% of the source" % (100.0 * i2["undefinedCells"] / out_layer, 100.0 * n2 / in_layer),
                     "kernel_ms_avg": t2, "Mcells_per_s": nz * out_layer / (t2 * 1e-3) / 1e6, "algorithmic_bytes_per_launch": b2, "n_src_bbox": n2,
                     "frac": b2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "tuned_shape": shape2, "tile": [i2.get("tileW"), i2.get("tileH")],
+                    "staged_cells_per_slice": i2.get("stagedCells"), "n_src_touched": workloads.touched_source_cells(px2, py2, wl2.inX, wl2.inY, 2),
+                    "frac_on_staged_bytes": (nz * 4 * (i2.get("stagedCells", 0) + out_layer) + i2["planBytes"]) / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "verified": (not bad2) if not args.no_verify else None,
                     "note": "output batch at the window chosen for the headline plan"}
                 if bad2:

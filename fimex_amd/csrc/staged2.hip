@@ -432,6 +432,33 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                     }
                     store_result(__float_as_uint(r), ro, cellOff[k], a.flags);
                 }
+            } else if constexpr (FAST) {
+                // float arithmetic: the stencil's columns are summed first, two at a time in packed FMAs -- the two floats a
+                // ds_read2_b32 delivers are one operand, the row's weight is the other (both halves) -- then the four column sums
+                // meet the x weights: 11 packed / scalar instructions per output instead of 20 FMAs.  The launch is bound by its
+                // instructions (LDS reads and arithmetic: 1.9 of 2.5 ms with the memory instructions switched off,
+                // profiles/r03_ablate_bicubic_fast.log), so this is where its time is.
+                using v2f = float __attribute__((ext_vector_type(2)));
+                // (the four floats of a stencil row are read as two ds_read2_b32: 8-byte LDS reads at 4-byte addresses work on this
+                // hardware but take five times as long, scripts/calib/lds_unaligned.hip, profiles/calib/r03_lds_unaligned.jsonl)
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    v2f c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* fr = reinterpret_cast<const float*>(curb + row[k][r]);
+                        const v2f f01 = {fr[0], fr[1]};
+                        const v2f f23 = {fr[2], fr[3]};
+                        const v2f myPair = {MYf[k][r & 2], MYf[k][(r & 2) + 1]};  // (a register pair; the packed FMA takes one half twice)
+                        const v2f my = (r & 1) ? __builtin_shufflevector(myPair, myPair, 1, 1) : __builtin_shufflevector(myPair, myPair, 0, 0);
+                        c01 = __builtin_elementwise_fma(f01, my, c01);
+                        c23 = __builtin_elementwise_fma(f23, my, c23);
+                    }
+                    const v2f x01 = {XMf[k][0], XMf[k][1]}, x23 = {XMf[k][2], XMf[k][3]};
+                    const v2f p = __builtin_elementwise_fma(x23, c23, x01 * c01);
+                    const float acc = p.x + p.y;
+                    store_result(__float_as_uint(PLAIN ? acc : pick(mUndef[k], undefined_f(), acc)), ro, cellOff[k], a.flags);
+                }
             } else {
     #pragma unroll
                 for (int k = 0; k < PER; ++k) {
@@ -442,15 +469,7 @@ __global__ void __launch_bounds__(NT) staged_apply2(Staged2Args a)
                         for (int j = 0; j < 4; ++j) f[r][j] = *reinterpret_cast<const float*>(curb + row[k][r] + 4 * j);
                     }
                     float acc = 0;  // interpolation.c:1005: accumulates into the float output
-                    if constexpr (FAST) {
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float xmf = 0;
-    #pragma unroll
-                            for (int j = 0; j < 4; ++j) xmf = __builtin_fmaf(XMf[k][j], f[r][j], xmf);
-                            acc = __builtin_fmaf(xmf, MYf[k][r], acc);
-                        }
-                    } else {
+                    {
     #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             double xmf = 0;

@@ -297,7 +297,10 @@ def main():
     # window -- what a plain allocation would have got -- and the cost of the probing are reported beside the metric.
     placement = None
     batch = None
-    if args.placements > 1 and d_full is None:
+    # (strong scaling over several GPUs: every rank's block is a send buffer of the overlapped write-back; those stay plain
+    # torch allocations on every rank -- the library's batches are mapped through HIP's virtual memory management, and what
+    # RCCL does with such buffers as peer-to-peer sources could not be tried on the one-GPU boxes this was developed on)
+    if args.placements > 1 and d_full is None and not (strong and dist_on):
         del d_out
         torch.cuda.empty_cache()
         try:
@@ -491,10 +494,12 @@ def main():
 def measure_weak_write_back(torch, dist, sharding, args, plan, stream, d_in, d_out, d_full, nz, nz_total, first, in_layer, out_layer, world, rank):
     """weak scaling: RCCL gather of every rank's finished slices to rank 0 over xGMI, after the regrid, outside the metric
     (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)."""
+    # (sent from a plain torch allocation: see the note on library-placed batches in main; the copy is made before the clock starts)
+    src = d_out.clone() if args.backend == "nccl" else d_out.cpu()
     dist.barrier()
     torch.cuda.synchronize()
     tg = time.perf_counter()
-    full = sharding.gather_slices(d_out if args.backend == "nccl" else d_out.cpu(), nz_total, dst=0)
+    full = sharding.gather_slices(src, nz_total, dst=0)
     torch.cuda.synchronize()
     dist.barrier()
     tg = time.perf_counter() - tg

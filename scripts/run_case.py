@@ -3,7 +3,7 @@
 that scripts/collect_case_profiles.py puts behind `rocprofv3 ... --` (and a stand-alone HIP-event measurement).
 usage: python scripts/run_case.py <case> [--reps N]
 cases: forward_mean_c4 forward_median_c4 rotate_values rotate_direction fill2d_nz16 creepfill_nz16 bilinear_short bicubic_short
-       typed_short_bilinear"""
+       bicubicfast_short typed_short_bilinear typed_short_nearest typed_uchar_bilinear typed_short_bilinear_short"""
 import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,21 +87,27 @@ def main():
             ts = timed(lambda: fa.creepfill2d_device(d.data_ptr(), nx, ny, nz, 20, 2, st), reset)
             r.update(workload="mifi_creepfill2d_f(repeat 20, setWeight 2) on %d slices of 3000x3000, 30 %% holes" % nz, kernel_pattern="fill")
         r.update(cells=nz * nx * ny, bytes_survey_8d=None, bytes_must_move=None, note="iteration dependent: time and sweeps, no roofline claim (SURVEY 8d)")
-    elif a.case in ("bilinear_short", "bicubic_short", "typed_short_bilinear"):
+    elif a.case in ("bilinear_short", "bicubic_short", "bicubicfast_short", "typed_short_bilinear", "typed_short_nearest", "typed_uchar_bilinear", "typed_short_bilinear_short"):
         wl = workloads.BilinearRotatedPole()
-        nz = 25 if a.case != "typed_short_bilinear" else 200
-        method = fa.BICUBIC if a.case == "bicubic_short" else fa.BILINEAR
-        plan, px, py = bench.build_plan(fa, torch, wl, method, st)
+        typed = a.case.startswith("typed_")
+        nz = 200 if (typed and not a.case.endswith("_short")) else 25
+        method = fa.BICUBIC if a.case.startswith("bicubic") else (fa.NEAREST_NEIGHBOR if a.case.endswith("nearest") else fa.BILINEAR)
+        plan, px, py = bench.build_plan(fa, torch, wl, method, st, bicubic=fa.BICUBIC_FAST if a.case == "bicubicfast_short" else None)
         info = plan.info()
         d_in = bench.make_slices(torch, wl.base_field(), nz)
         out = wl.outX * wl.outY
-        if a.case == "typed_short_bilinear":
-            d_s = ((d_in - 280) * 100).nan_to_num(-32767).to(torch.int16)
-            d_o = torch.empty((nz, wl.outY, wl.outX), dtype=torch.int16, device="cuda")
+        if typed:
+            if "uchar" in a.case:
+                d_s = ((d_in - 200) * 1.2).nan_to_num(0.0).clamp(0, 255).to(torch.uint8); code, bad, eb = fa.CDM_UCHAR, 0.0, 1
+            else:
+                d_s = ((d_in - 280) * 100).nan_to_num(-32767).to(torch.int16); code, bad, eb = fa.CDM_SHORT, -32767.0, 2
+            d_o = torch.empty((nz, wl.outY, wl.outX), dtype=d_s.dtype, device="cuda")
             del d_in
-            ts = timed(lambda: fa.regrid_apply_typed_device(plan, d_s.data_ptr(), fa.CDM_SHORT, nz, -32767.0, d_o.data_ptr(), st))
-            r.update(workload="packed shorts, 200 slices, bilinear, fused conversion (SURVEY 8f n1)", kernel_pattern="_apply",
-                     bytes_survey_8d=nz * 2 * (wl.inX * wl.inY + out) + info["planBytes"])
+            ts = timed(lambda: fa.regrid_apply_typed_device(plan, d_s.data_ptr(), code, nz, bad, d_o.data_ptr(), st))
+            # the plan bytes of the stored-type form: LDS offsets (4 B) and the two fractions (8 B) per cell, the chunk lists are small
+            plan_bytes = (12 if method == fa.BILINEAR else 4) * out
+            r.update(workload="%s, %d slices, %s, fused conversion (SURVEY 8f n1)" % ("packed shorts" if eb == 2 else "unsigned bytes", nz, a.case.split("_")[2]),
+                     kernel_pattern="_apply", bytes_survey_8d=nz * eb * (wl.inX * wl.inY + out) + plan_bytes)
         else:
             d_out = torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
             ts = timed(lambda: plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), st))

@@ -2231,6 +2231,31 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v3(CreepV2Args
     }
 }
 
+// A grid whose workgroups wait for each other: all of them have to be resident at once.  hipLaunchCooperativeKernel checks the grid
+// against the occupancy query and then launches like any other launch -- plain, cooperative and graph launches give identical
+// residency (MI355X_MICROARCH.md, residency and cooperative launch).  The same check is made here and the launch is a plain one:
+// 15-19 us less per call, and a process that is being profiled no longer dies in its exit handlers (rocprofv3 7.2 ends with
+// SIGSEGV inside exit() after any cooperative launch, after its output is complete: profiles/r03_fill2d_nz16_abnormal_exit.txt).
+// FILL_COOP=1 (tuning build) brings the cooperative launch back.  false: not every workgroup would be resident.
+bool launch_resident(const void* kernel, dim3 grid, dim3 block, void** params, size_t ldsBytes, hipStream_t stream)
+{
+    if (tuning("FILL_COOP", 0) != 0) {
+        if (hipLaunchCooperativeKernel(kernel, grid, block, params, (unsigned int)ldsBytes, stream) == hipSuccess) return true;
+        (void)hipGetLastError();
+        return false;
+    }
+    int perCu = 0, dev = 0, cus = 0;
+    FA_HIP(hipGetDevice(&dev));
+    FA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, (int)block.x, ldsBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if ((size_t)perCu * (size_t)cus < (size_t)grid.x * grid.y * grid.z) return false;
+    FA_HIP(hipLaunchKernel(kernel, grid, block, params, ldsBytes, stream));
+    return true;
+}
+
 void collect_stats(const DeviceArray<SliceStats>& d_stats, size_t nz, size_t* h_nChanged, hipStream_t stream, const char* what)
 {
     std::vector<SliceStats> st(nz);
@@ -2335,12 +2360,8 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
             allow_dynamic_lds(kernel, mlds);
             void* params[] = {&a};
             const dim3 grid((uint32_t)(kXcds * groups * perXcd));
-            // cooperative: every workgroup of the grid is resident (they wait for each other), or the launch is refused -- then
-            // one workgroup per slice does the work
-            if (hipLaunchCooperativeKernel(kernel, grid, dim3(mwaves * kWave), params, (unsigned int)mlds, stream) != hipSuccess) {
-                (void)hipGetLastError();
-                groups = 1;
-            }
+            // every workgroup of the grid resident (they wait for each other), or one workgroup per slice does the work
+            if (!launch_resident(kernel, grid, dim3(mwaves * kWave), params, mlds, stream)) groups = 1;
         }
         if (groups <= 1) {
             auto launch = [&](auto kernel) {
@@ -2431,11 +2452,8 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
             const void* kernel = reinterpret_cast<const void*>(&creepfill_kernel_v3);
             allow_dynamic_lds(kernel, ldsBytes);
             void* params[] = {&a};
-            if (hipLaunchCooperativeKernel(kernel, dim3((uint32_t)(kXcds * groups * perXcd)), dim3(kCreepThreads), params, (unsigned int)ldsBytes, stream) !=
-                hipSuccess) {  // refused (not every workgroup would be resident): one workgroup per slice
-                (void)hipGetLastError();
-                groups = 1;
-            }
+            if (!launch_resident(kernel, dim3((uint32_t)(kXcds * groups * perXcd)), dim3(kCreepThreads), params, ldsBytes, stream))
+                groups = 1;  // not every workgroup would be resident: one workgroup per slice
         }
         if (groups <= 1) {
             allow_dynamic_lds(reinterpret_cast<const void*>(&creepfill_kernel_v2), ldsBytes);

@@ -139,7 +139,8 @@ __device__ __forceinline__ float median_by_rank(const FwdArgs& a, uint32_t b, ui
 // one lane per target cell.  Workgroups are dealt round-robin over the 8 XCDs; XCD x takes the x-th eighth of the target
 // cells (blocks of 256 consecutive cells), so that a source line -- whose cells map to neighbouring targets in several target
 // rows -- is fetched into ONE L2 instead of into all eight (configs[3]: 1.85 GB -> about 1.1 GB of fabric traffic per 100 slices).
-template <int KIND, bool UNDEF, int ZC>
+// RANK (median only): some bucket of the plan holds more than two cells; without it the rank-counting path is not compiled in
+template <int KIND, bool UNDEF, int ZC, bool RANK = false>
 __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 {
     const uint32_t perXcd = gridDim.x / kXcds;  // the grid holds 8 * perXcd workgroups per z chunk
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
     const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
     const uint32_t b = a.offsets[t], e = a.offsets[t + 1];
     const uint32_t i0 = (e > b) ? a.src[b] : 0u;
-    if (KIND == 5 && (e - b > 2 || (kTuningBuild && a.rankAll != 0))) {
+    if (KIND == 5 && RANK && (e - b > 2 || (kTuningBuild && a.rankAll != 0))) {
         // median of a bucket of three or more source cells: value of rank size()/2 (std::nth_element, :49-53) by rank counting, slice
         // by slice -- no scratch memory, any bucket size; the other lanes of the wave (buckets of at most two cells, by far the
         // most in practice: DESIGN.md gives the occupancy histogram) take the batched path below
@@ -377,8 +378,16 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     case Aggregate::Median:
         // buckets of at most two cells: eight slices in flight, no rank counting; longer ones are ranked slice by slice by the same kernel
         // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
-        if (u) forward_apply_lane<5, true, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
-        else forward_apply_lane<5, false, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
+        if (plan.info.maxBucket > 2 || a.rankAll != 0) {
+            if (u) forward_apply_lane<5, true, kLaneZc, true><<<gridLane, kBlock, 0, stream>>>(a);
+            else forward_apply_lane<5, false, kLaneZc, true><<<gridLane, kBlock, 0, stream>>>(a);
+        } else if (tuning("FWD_MEDIAN_ZC", 8) == 4) {
+            if (u) forward_apply_lane<5, true, 4><<<gridLane, kBlock, 0, stream>>>(a);
+            else forward_apply_lane<5, false, 4><<<gridLane, kBlock, 0, stream>>>(a);
+        } else {
+            if (u) forward_apply_lane<5, true, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
+            else forward_apply_lane<5, false, kLaneZc><<<gridLane, kBlock, 0, stream>>>(a);
+        }
         break;
     }
     FA_HIP(hipGetLastError());

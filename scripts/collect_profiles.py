@@ -51,7 +51,7 @@ def main():
     tr = list(csv.DictReader(open(glob.glob(work + "/trace/**/*_kernel_trace.csv", recursive=True)[0])))
     t = timed_dispatches(tr, "Kernel_Name")
     dur = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-6 for x in t]
-    timed = {"kernel": t[0]["Kernel_Name"].split("(")[0][-80:] if t else None, "launches": len(dur), "ms_avg": sum(dur) / max(len(dur), 1),
+    timed = {"kernel": t[0]["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0] if t else None, "launches": len(dur), "ms_avg": sum(dur) / max(len(dur), 1),
              "ms_min": min(dur or [0]), "ms_max": max(dur or [0]), "bench_kernel_ms_avg": b["roofline"]["kernel_ms_avg"], "bench_ms_per_step": b["ms_per_step"],
              "bench_frac": b["roofline"]["frac"], "output_placement": b["config"].get("output_placement"), "tuned_shape": b["config"].get("tuned_shape"),
              "how": "the %d launches of the staged apply kernel that precede the first gather-kernel launch (the verification) in the per-dispatch trace" % STEPS}

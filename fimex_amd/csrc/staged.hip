@@ -2,7 +2,7 @@
 //
 // Same arithmetic as bilinear_apply / bicubic_apply in regrid.hip (src/interpolation.c:881-1028), different data
 // movement.  A per-lane gather of the stencil straight from global memory asks the memory system for the same
-// 128-byte lines several times (measured on the 4000x3000 -> 2000x2000 rotated-pole case, profiles/r01_*: 3x the
+// 128-byte lines several times (measured on the 4000x3000 -> 2000x2000 rotated-pole case, profiles/LAB_NOTES_r01_r02.md, round 1: 3x the
 // ideal L2 requests and 1.6x the ideal fabric reads for the 2x2 stencil; the 4x4 stencil ran at 17 % of the HBM
 // roofline), because a wave's lanes stride through the source and neighbouring workgroups share lines but not
 // their timing.  Here a workgroup owns a TW x TH tile of OUTPUT cells; the SOURCE cells that tile needs form a
@@ -14,7 +14,7 @@
 //   2. the current buffer is interpolated: stencils come from LDS (ds_read2_b32 pairs), and every wave writes
 //      256 contiguous bytes of output per store, non-temporal.
 // The per-output plan entry is two (bilinear) or four (bicubic) 16-bit LDS row offsets; the fractions are the ones of
-// the gather plan.  Measured and kept out (profiles/r01_sweep*.log): register staging instead of LDS-DMA (equal),
+// the gather plan.  Measured and kept out (round 1's sweeps, profiles/LAB_NOTES_r01_r02.md): register staging instead of LDS-DMA (equal),
 // 2-4 slices of prefetch depth (equal), non-temporal loads (-15 %), plain stores (-6 %), XCD-contiguous or striped
 // tile orders (equal or worse than plain round-robin).
 #include "plan.hpp"

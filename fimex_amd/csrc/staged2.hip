@@ -1004,7 +1004,7 @@ bool build_staged2_shape(fimex_amd_regrid_plan& plan, Staged2Plan& target, int n
     if (plan.outX * plan.outY == 0) return false;
     // the float form of the bicubic stencil is as light as the bilinear one: it takes the bilinear shapes
     const bool cubic = plan.kind == PlanKind::Bicubic && !plan.bicubicFast;
-    // measured on the benchmark plan (profiles/r02_sweep_[c-x]*.log): 1024 threads on 512 x 8 tiles (one workgroup per CU) for the
+    // measured on the benchmark plan (round 2's sweeps, profiles/LAB_NOTES_r01_r02.md): 1024 threads on 512 x 8 tiles (one workgroup per CU) for the
     // 1 x 1 and 2 x 2 stencils.  With the tile-major launch order 512 threads on 256 x 8 tiles (two workgroups per CU) run the
     // bilinear launch 2.5-3.5 % faster on two boxes (2.19 against 2.27 ms) and 4 % slower on two others (2.41 against 2.31 ms), and
     // lose on the 1 x 1 stencil and on short batches everywhere: the shape that behaves the same on every box is kept.  The 4 x 4
@@ -1051,7 +1051,7 @@ bool build_staged2_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     if (plan.kind == PlanKind::Bilinear && plan.staged2.nt == 1024 && tuning("STAGE2_ALT", 1) != 0)
         build_staged2_shape(plan, plan.staged2Alt, 512, d_px, d_py, stream);
     // likewise the 4 x 4 stencil in float arithmetic: 256 threads on 128 x 8 tiles (three workgroups per CU) beside 512 threads on
-    // 256 x 8 (2.38 against 2.41 ms in one process, profiles/r02_sweep_bicubicfast.log)
+    // 256 x 8 (2.38 against 2.41 ms in one process, round 2, profiles/LAB_NOTES_r01_r02.md)
     if (plan.kind == PlanKind::Bicubic && plan.bicubicFast && plan.staged2.nt == 512 && tuning("STAGE2_ALT", 1) != 0)
         build_staged2_shape(plan, plan.staged2Alt, 256, d_px, d_py, stream);
     return true;
@@ -1086,7 +1086,7 @@ void launch_staged2_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     // z chunks.  Tile-major order (the default, STAGE2_ORDER 1): the chunks of a tile are consecutive workgroups of one XCD, so
     // they start together and fetch the tile's per-output plan -- 12 bytes per cell, 0.05 GB per chunk of the benchmark
     // launch -- once from memory instead of once per chunk, and the chip as a whole works on eight neighbouring tile rows;
-    // chunks of one size (about STAGE2_ZPB slices).  Measured on the benchmark plan (profiles/r02_sweep_[n-r].log): bilinear
+    // chunks of one size (about STAGE2_ZPB slices).  Measured on the benchmark plan (round 2's sweeps, profiles/LAB_NOTES_r01_r02.md): bilinear
     // 2.40 -> 2.32 ms, nearest 2.32 -> 2.21 ms, 25 slices 0.322 -> 0.303 ms.
     // Chunk-major order (STAGE2_ORDER 0, round 1 and early round 2): all tiles of chunk 0, then chunk 1, ...; the chunks shrink
     // towards the end of the launch so that the last workgroups are short ones (STAGE2_ZTAIL).

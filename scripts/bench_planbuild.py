@@ -34,4 +34,4 @@ for _ in range(4):
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 print(json.dumps({"step": "vector reproject matrix", "cells": n, "ms": min(ts[1:]) * 1e3}), flush=True)
 # The CPU side of this comparison (numpy projection + C axis positions on one core: 346 + 188 ms, positions equal to 5e-12) was
-# measured once through tests' oracle and is recorded in profiles/r01_planbuild.jsonl; scripts do not touch oracle/.
+# measured once through tests' oracle and is recorded in the round-1 notes (profiles/LAB_NOTES_r01_r02.md); scripts do not touch oracle/.

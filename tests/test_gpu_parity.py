@@ -326,6 +326,39 @@ def test_stored_type_regrid_on_random_shapes(fa):
         plan.close()
 
 
+@pytest.mark.parametrize("method", [oracle.BILINEAR, oracle.NEAREST])
+@pytest.mark.parametrize("dt", [np.int16, np.uint16, np.int8, np.uint8])
+@pytest.mark.parametrize("outX,bad", [(212, "min"), (213, "max"), (212, None), (77, "max")])
+def test_stored_types_second_staged_form_edges(fa, method, dt, outX, bad):
+    """The second staged form on stored types (staged2.hip: staged_apply2_typed), where its special cases lie: even row lengths
+    (two results per store) and odd ones (one per store, pairs that straddle rows), no fill value at all (NaN: nothing is ever
+    undefined on input), fill values at either end of the type's range, an output buffer that is not 4-byte aligned, and data that
+    use the type's whole range (rounding at the ends).  Against the oracle's three steps, element for element."""
+    import torch
+    inX, inY, outY, nz = 336, 97, 45, 9
+    px, py = cases.backward_positions(inX, inY, outX, outY, seed=outX)
+    info = np.iinfo(dt)
+    badv = float("nan") if bad is None else float(info.min if bad == "min" else info.max)
+    rng = np.random.default_rng(outX + int(np.dtype(dt).itemsize))
+    f = rng.integers(info.min, int(info.max) + 1, (nz, inY, inX)).astype(dt)
+    if bad is not None:
+        f.reshape(-1)[rng.random(f.size) < 0.03] = dt(badv)
+    code = oracle.cdm_type_of(dt)
+    fl = oracle.interpolate_values(method, px, py, oracle.data2interpolation_array(f, badv), inX, inY, outX, outY)
+    want = oracle.interpolation_array2data(fl, code, badv)
+    # without a fill value an undefined result becomes (T)NaN, which C leaves undefined: those cells are not compared
+    defined = np.ones(fl.shape, bool) if bad is not None else ~np.isnan(fl)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    assert plan.info()["stagedCells"] > 0
+    t = torch.from_numpy(f.view(np.uint8)).cuda()
+    for shift in (0, np.dtype(dt).itemsize):  # the second run writes to an address that is not a multiple of 4
+        out = torch.zeros(want.nbytes + 8, dtype=torch.uint8, device="cuda")
+        fa.regrid_apply_typed_device(plan, t.data_ptr(), code, nz, badv, out.data_ptr() + shift)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()[shift:shift + want.nbytes].view(dt).reshape(want.shape)
+        assert np.array_equal(got[defined], want[defined]), (np.dtype(dt).name, method, outX, bad, shift, int((got != want)[defined].sum()))
+
+
 def test_sor_error_is_the_reference_expression(fa):
     """fill2d's step takes one fused multiply-add where the reference goes through double (fill.hip, sor_error): fields whose
     neighbours lie up to 60 binades apart, subnormals and values next to the float range's end put every regime of the two

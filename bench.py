@@ -20,9 +20,11 @@ After the timed steps (outside the timed region) slices 0, NZ/2 and NZ-1 of the 
 for bit with the CPU oracle, and EVERY slice of it with the same batch regridded once more by the per-lane gather kernels
 (fimex_amd_regrid_apply_gather_device) into a second buffer; a mismatch makes the run fail.
 
-The output batch is allocated by the library (fimex_amd_regrid_batch_alloc_device: the batch is tried at --placements windows of
-one reserved range, the fastest stays, the others' memory goes back to the driver); what a plain allocation would have got
-(the first window) and the cost of the probing are reported in config.output_placement.  --placements 1 = plain allocation.
+Both batches are allocated by the library: the source batch (fimex_amd_regrid_source_batch_alloc_device: --source-candidates whole
+allocations timed with the plan's launch, the fastest kept) and the output batch (fimex_amd_regrid_batch_alloc_device: tried at
+--placements windows of one reserved range, the fastest stays, the others' memory goes back to the driver); what plain
+allocations would have got (the first candidate / window) and the cost of the probing are reported in config.source_placement and
+config.output_placement.  --placements 1 = plain allocations for both.
 """
 import argparse
 import json
@@ -133,10 +135,10 @@ def build_plan(fa, torch, wl, method, stream, bicubic=None):
     return plan, d_px.cpu().numpy(), d_py.cpu().numpy()
 
 
-def make_slices(torch, base, nz, first=0):
-    """slice k = base + 0.01 (first + k), resident in HBM ([nz][inY][inX] f32)."""
+def make_slices(torch, base, nz, first=0, into=None):
+    """slice k = base + 0.01 (first + k), resident in HBM ([nz][inY][inX] f32); into: a tensor of that shape to fill."""
     d_base = torch.from_numpy(base).cuda()
-    d_in = torch.empty((nz,) + base.shape, dtype=torch.float32, device="cuda")
+    d_in = into if into is not None else torch.empty((nz,) + base.shape, dtype=torch.float32, device="cuda")
     for k0 in range(0, nz, 16):
         k1 = min(nz, k0 + 16)
         off = 0.01 * torch.arange(first + k0, first + k1, dtype=torch.float32, device="cuda")
@@ -219,6 +221,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-slice, copy and gather measurements")
     ap.add_argument("--placements", type=int, default=8,
                     help="windows the library tries for the output batch (fimex_amd_regrid_batch_alloc_device; 1 = plain allocation)")
+    ap.add_argument("--source-candidates", type=int, default=4,
+                    help="allocations the library tries for the source batch (fimex_amd_regrid_source_batch_alloc_device; 1 = plain allocation)")
     ap.add_argument("--workload", default="default", choices=["default", "one_percent"],
                     help="target axes: round 1's (10.9 %% of the target cells undefined) or the ~1 %% variant of SURVEY 8d")
     ap.add_argument("--no-tune", action="store_true", help="keep the plan's default workgroup shape (skip fimex_amd_regrid_plan_tune_device)")
@@ -285,7 +289,22 @@ def main():
     if nz == 0:
         raise SystemExit("bench.py: rank %d holds no slice (%d slices over %d ranks)" % (rank, nz_total, world))
     out_layer, in_layer = wl.outX * wl.outY, wl.inX * wl.inY
-    d_in = make_slices(torch, base, nz, first)
+    # The source batch comes from the library too (fimex_amd_regrid_source_batch_alloc_device): which allocation the source slices
+    # lie in moves the launch by 4-5 %, more than the output's placement does (profiles/calib/r03_placement_matrix.jsonl).  A
+    # resident pipeline asks the library for the buffer its reader fills; here the synthetic slices are written into it.
+    source_placement, src_batch = None, None
+    if args.placements > 1 and args.source_candidates > 1:
+        try:
+            src_batch = plan.alloc_source_batch(nz, candidates=args.source_candidates, stream=stream)
+            si = src_batch.info
+            source_placement = {"by": "fimex_amd_regrid_source_batch_alloc_device", "candidates": si["positions"], "chosen": si["chosen"],
+                                "ms_at_each": si["msAtPosition"], "ms_at_first_candidate": si["msAtPosition"][0] if si["msAtPosition"] else None,
+                                "bytes_allocated_while_probing": si["bytesProbed"], "bytes_held_afterwards": si["bytesHeld"],
+                                "probe_seconds": si["probeSeconds"],
+                                "note": "whole allocations, zero-filled, default workgroup shape, median of 3 launches each into a scratch output"}
+        except fa.FimexAmdError as e:
+            log("bench.py: no source placement (%s)" % str(e).splitlines()[0])
+    d_in = make_slices(torch, base, nz, first, into=src_batch.as_tensor() if src_batch is not None else None)
     # rank 0 holds the job's whole output in strong mode (the write-back target); its own block is a view of it
     d_full = torch.empty((nz_total, wl.outY, wl.outX), dtype=torch.float32, device="cuda") if (strong and rank == 0 and dist_on) else None
     d_out = d_full[first:last] if d_full is not None else torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
@@ -390,7 +409,7 @@ def main():
                         % (args.method, args.nz, "split over the GPUs" if strong else "per GPU"),
             "slices_per_gpu": nz, "slices_total": nz_total, "library": "libfimex_amd_tuning.so" if args.tuning_build else "libfimex_amd.so",
             "sharding": "slices over GPUs, plan replicated, no data-path collective",
-            "plan_build_s": t_plan, "tuned_shape": tuned_shape, "output_placement": placement, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
+            "plan_build_s": t_plan, "tuned_shape": tuned_shape, "source_placement": source_placement, "output_placement": placement, "undefined_target_cells": info["undefinedCells"], "border_cells": info["borderCells"],
         },
         "verified_slices": verified, "verified_all_slices_vs_gather": (not args.no_verify) or None, "verified_how": "1e-5 of the slice's largest magnitude (FIMEX_AMD_BICUBIC_FAST)" if fast else "bit for bit against the CPU oracle",
         "roofline": {

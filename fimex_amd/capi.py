@@ -77,6 +77,7 @@ SYMBOLS = {
     "fimex_amd_regrid_plan_tune_device": (ctypes.c_int, [_V, _V, _Z, _V, _V, ctypes.POINTER(ctypes.c_int)]),
     "fimex_amd_regrid_apply_gather_device": (ctypes.c_int, [_V, _V, _Z, _V, _V]),
     "fimex_amd_regrid_batch_alloc_device": (ctypes.c_int, [_V, _V, _Z, ctypes.c_int, _V, ctypes.POINTER(_V)]),
+    "fimex_amd_regrid_source_batch_alloc_device": (ctypes.c_int, [_V, _Z, ctypes.c_int, _V, ctypes.POINTER(_V)]),
     "fimex_amd_batch_get_info": (ctypes.c_int, [_V, ctypes.POINTER(BatchInfo)]),
     "fimex_amd_batch_free": (ctypes.c_int, [_V]),
     "fimex_amd_regrid_slice_host": (ctypes.c_int, [_V, _F, _Z, ctypes.c_float, ctypes.POINTER(Process2d), _Z, _F, ctypes.c_float,
@@ -265,6 +266,10 @@ class RegridPlan:
         """The same regrid through the per-lane gather kernels (cross-check of the staged kernels on whole batches)."""
         _check(load().fimex_amd_regrid_apply_gather_device(self._h, d_in, nz, d_out, stream))
 
+    def alloc_source_batch(self, nz, candidates=4, stream=0):
+        """Source batch [nz][inY][inX] placed by the library (fimex_amd_regrid_source_batch_alloc_device), zero-filled."""
+        return Batch(self, 0, nz, candidates, stream, source=True)
+
     def alloc_batch(self, d_in, nz, positions=8, stream=0):
         """Output batch [nz][outY][outX] placed by the library (fimex_amd_regrid_batch_alloc_device)."""
         return Batch(self, d_in, nz, positions, stream)
@@ -279,15 +284,18 @@ class RegridPlan:
 class Batch:
     """fimex_amd_batch: device memory of one output batch, placed where the plan's apply launch runs fastest."""
 
-    def __init__(self, plan, d_in, nz, positions=8, stream=0):
+    def __init__(self, plan, d_in, nz, positions=8, stream=0, source=False):
         self._h = _V()
-        _check(load().fimex_amd_regrid_batch_alloc_device(plan._h, d_in, nz, positions, stream, ctypes.byref(self._h)))
+        if source:  # the SOURCE batch [nz][inY][inX]: `positions` whole allocations tried (d_in is not used)
+            _check(load().fimex_amd_regrid_source_batch_alloc_device(plan._h, nz, positions, stream, ctypes.byref(self._h)))
+        else:
+            _check(load().fimex_amd_regrid_batch_alloc_device(plan._h, d_in, nz, positions, stream, ctypes.byref(self._h)))
         i = BatchInfo()
         _check(load().fimex_amd_batch_get_info(self._h, ctypes.byref(i)))
         self.info = {k: getattr(i, k) for k, _ in BatchInfo._fields_ if k != "msAtPosition"}
         self.info["msAtPosition"] = [float(i.msAtPosition[k]) for k in range(i.positions)] if i.positions > 1 else []
         self.data_ptr = i.d_data
-        self.nz, self.outY, self.outX = nz, plan.outY, plan.outX
+        self.nz, self.outY, self.outX = (nz, plan.inY, plan.inX) if source else (nz, plan.outY, plan.outX)
 
     def as_tensor(self):
         """The batch as a torch tensor [nz][outY][outX] (no copy; keep this object alive as long as the tensor)."""

@@ -175,6 +175,85 @@ fimex_amd_batch* batch_alloc(const fimex_amd_regrid_plan& plan, const float* d_i
     return b.release();
 }
 
+// The SOURCE batch [nz][inY][inX] of a resident pipeline.  Which allocation the source slices lie in moves the apply launch more than
+// the output's does (profiles/calib/r03_placement_matrix.jsonl: five source batches x five output batches, each its own allocation:
+// 2.32-2.34 ms with three of the sources, 2.42-2.47 ms with the other two, whatever the output), and windows a few hundred MiB apart
+// share most of their memory for a batch of this size: the candidates are whole allocations here (hipMalloc: one region each), all
+// held at once so that they are different memory, filled with zeros, timed with the plan's launch into a scratch output; the
+// fastest stays, the others are freed before the call returns.
+fimex_amd_batch* batch_alloc_source(const fimex_amd_regrid_plan& plan, size_t nz, int candidates, hipStream_t stream)
+{
+    FA_REQUIRE(candidates >= 1 && candidates <= FIMEX_AMD_BATCH_MAX_POSITIONS, "candidates must be 1 .. 16");
+    const size_t bytes = nz * plan.inX * plan.inY * sizeof(float), outBytes = nz * plan.outX * plan.outY * sizeof(float);
+    FA_REQUIRE(bytes > 0, "empty batch");
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t freeB = 0, totalB = 0;
+    FA_HIP(hipMemGetInfo(&freeB, &totalB));
+    while (candidates > 1 && (size_t)candidates * bytes + outBytes + (size_t(2) << 30) > freeB) --candidates;
+    std::vector<void*> cand((size_t)candidates, nullptr);
+    void* scratch = nullptr;
+    auto b = std::make_unique<fimex_amd_batch>();
+    b->device = plan.device;
+    fimex_amd_batch_info& info = b->info;
+    info.bytes = bytes;
+    info.positions = candidates;
+    info.chosen = 0;
+    auto release = [&](int keep) {
+        for (int c = 0; c < (int)cand.size(); ++c)
+            if (c != keep && cand[c]) { (void)hipFree(cand[c]); cand[c] = nullptr; }
+        if (scratch) { (void)hipFree(scratch); scratch = nullptr; }
+    };
+    try {
+        for (int c = 0; c < candidates; ++c) {
+            FA_HIP(hipMalloc(&cand[c], bytes));
+            FA_HIP(hipMemsetAsync(cand[c], 0, bytes, stream));
+        }
+        info.bytesProbed = (size_t)candidates * bytes;
+        if (candidates > 1) {
+            FA_HIP(hipMalloc(&scratch, outBytes));
+            info.bytesProbed += outBytes;
+            hipEvent_t e0, e1;
+            FA_HIP(hipEventCreate(&e0));
+            FA_HIP(hipEventCreate(&e1));
+            try {
+                for (int c = 0; c < candidates; ++c) {
+                    float ms[3];
+                    for (int rep = 0; rep < 4; ++rep) {
+                        FA_HIP(hipEventRecord(e0, stream));
+                        apply_plan_device(plan, static_cast<const float*>(cand[c]), nz, static_cast<float*>(scratch), stream);
+                        FA_HIP(hipEventRecord(e1, stream));
+                        FA_HIP(hipEventSynchronize(e1));
+                        if (rep > 0) FA_HIP(hipEventElapsedTime(&ms[rep - 1], e0, e1));
+                    }
+                    std::sort(ms, ms + 3);
+                    info.msAtPosition[c] = ms[1];
+                    if (ms[1] < info.msAtPosition[info.chosen]) info.chosen = c;
+                }
+            } catch (...) {
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                throw;
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        FA_HIP(hipStreamSynchronize(stream));
+    } catch (...) {
+        release(-1);
+        throw;
+    }
+    release(info.chosen);
+    b->vmm = false;
+    b->base = static_cast<char*>(cand[(size_t)info.chosen]);
+    b->reserved = bytes;
+    info.d_data = b->base;
+    info.bytesHeld = bytes;
+    info.stepBytes = 0;
+    info.trimmed = 1;
+    info.probeSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return b.release();
+}
+
 const fimex_amd_batch_info& batch_info(const fimex_amd_batch& b) { return b.info; }
 
 void batch_free(fimex_amd_batch* b)

@@ -161,7 +161,7 @@ int fimex_amd_release_caches(void)
     return c_guard([&] { release_host_pipes(); });
 }
 
-int fimex_amd_abi_version(void) { return 130; }  // 1.30: output batches placed by the library, the gather cross-check
+int fimex_amd_abi_version(void) { return 131; }  // 1.31: source and output batches placed by the library, the gather cross-check
 
 int fimex_amd_device_count(void) { return usable_device_count(); }
 
@@ -352,6 +352,17 @@ int fimex_amd_regrid_batch_alloc_device(const fimex_amd_regrid_plan* plan, const
         FA_REQUIRE(plan != nullptr, "NULL plan");
         require_current_device(plan->device);
         *batch = batch_alloc(*plan, d_in, nz, positions, as_stream(stream));
+    });
+}
+
+int fimex_amd_regrid_source_batch_alloc_device(const fimex_amd_regrid_plan* plan, size_t nz, int candidates, void* stream, fimex_amd_batch** batch)
+{
+    return c_guard([&] {
+        FA_REQUIRE(batch != nullptr, "batch output pointer is NULL");
+        *batch = nullptr;
+        FA_REQUIRE(plan != nullptr, "NULL plan");
+        require_current_device(plan->device);
+        *batch = batch_alloc_source(*plan, nz, candidates, as_stream(stream));
     });
 }
 

@@ -184,6 +184,7 @@ void run_scan_sum(const float* d_values, size_t n, int mode, double average, int
 
 // batch.hip: output batches placed by the library
 fimex_amd_batch* batch_alloc(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, int positions, hipStream_t stream);
+fimex_amd_batch* batch_alloc_source(const fimex_amd_regrid_plan& plan, size_t nz, int candidates, hipStream_t stream);
 void batch_free(fimex_amd_batch* batch);
 const fimex_amd_batch_info& batch_info(const fimex_amd_batch& batch);
 void apply_plan_device(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);

@@ -53,7 +53,7 @@ def main():
     dur = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-6 for x in t]
     timed = {"kernel": t[0]["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0] if t else None, "launches": len(dur), "ms_avg": sum(dur) / max(len(dur), 1),
              "ms_min": min(dur or [0]), "ms_max": max(dur or [0]), "bench_kernel_ms_avg": b["roofline"]["kernel_ms_avg"], "bench_ms_per_step": b["ms_per_step"],
-             "bench_frac": b["roofline"]["frac"], "output_placement": b["config"].get("output_placement"), "tuned_shape": b["config"].get("tuned_shape"),
+             "bench_frac": b["roofline"]["frac"], "source_placement": b["config"].get("source_placement"), "output_placement": b["config"].get("output_placement"), "tuned_shape": b["config"].get("tuned_shape"),
              "how": "the %d launches of the staged apply kernel that precede the first gather-kernel launch (the verification) in the per-dispatch trace" % STEPS}
     json.dump(timed, open(os.path.join(out, "%s_%s_timed.json" % (tag, name)), "w"), indent=1)
     pmc = {"kernel": timed["kernel"], "launches_counted": STEPS}

@@ -8,6 +8,8 @@ profiles/calib/r02_placement*.jsonl):
             tuning build).  Prints one JSON line per window.  This is also the program profiled by `pmc`.
   realloc   the output batch freed and allocated again behind other allocations of varying size (a fresh torch allocation per
             trial): one JSON line per trial.
+  matrix    K source batches x K output batches, every one its own allocation: the launch time of every pair (does the source's
+            allocation matter as the output's does?).
   pmc       runs `windows` under rocprofv3 --pmc, one pass (= one process) per counter group, keeps the PER-INSTANCE values of
             every counter (JSON output) and relates them to the launch time of each window: which counter moves with the time?
             Writes <out>_<group>.json (per window: ms, per-counter sum / max / min over instances, the instance vector) and
@@ -94,6 +96,29 @@ def mode_realloc(args):
         del out
         keep.append(torch.empty((t + 1) * 300 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda"))  # shifts the next one
         torch.cuda.empty_cache()
+
+
+def mode_matrix(args):
+    """Does the SOURCE batch's allocation matter too?  K source batches and K output batches, each its own allocation (separate
+    hipMalloc calls: different physical memory), the launch timed for every pair."""
+    np, torch, fa, wl, plan, st, bench = setup(False)
+    nz, K = args.nz, args.trials
+    nout = nz * wl.outX * wl.outY
+    first = bench.make_slices(torch, wl.base_field(), nz)
+    srcs, outs, spacers = [first], [], []
+    for k in range(1, K):
+        spacers.append(torch.empty((k * 173) << 20, dtype=torch.uint8, device="cuda"))  # shifts what the allocator hands out next
+        srcs.append(first.clone())
+    for k in range(K):
+        spacers.append(torch.empty((k * 211 + 64) << 20, dtype=torch.uint8, device="cuda"))
+        outs.append(torch.empty(nout, dtype=torch.float32, device="cuda"))
+    print(json.dumps({"sources": [hex(t.data_ptr()) for t in srcs], "outputs": [hex(t.data_ptr()) for t in outs]}), flush=True)
+    for i, src in enumerate(srcs):
+        row = []
+        for j, out in enumerate(outs):
+            ms, _ = median_ms(np, torch, plan, src, nz, out.data_ptr(), st, args.reps)
+            row.append(round(ms, 4))
+        print(json.dumps({"source": i, "ms_by_output": row}), flush=True)
 
 
 def parse_counter_json(path):
@@ -187,7 +212,7 @@ def main():
         i = argv.index("--")
         argv, groups = argv[:i], argv[i + 1:]
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["windows", "realloc", "pmc"])
+    ap.add_argument("mode", choices=["windows", "realloc", "pmc", "matrix"])
     ap.add_argument("--positions", type=int, default=10)
     ap.add_argument("--step-mib", type=int, default=704)
     ap.add_argument("--reps", type=int, default=4)
@@ -201,6 +226,8 @@ def main():
         mode_windows(args)
     elif args.mode == "realloc":
         mode_realloc(args)
+    elif args.mode == "matrix":
+        mode_matrix(args)
     else:
         mode_pmc(args, groups or ["TCC_EA0_RDREQ TCC_EA0_RDREQ_LEVEL", "TCC_EA0_WRREQ TCC_EA0_WRREQ_STALL", "TCC_EA0_WRREQ_LEVEL TCC_TOO_MANY_EA_WRREQS_STALL",
                                   "TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_EA0_WRREQ_DRAM_CREDIT_STALL"])

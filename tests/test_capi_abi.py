@@ -41,7 +41,7 @@ def test_header_is_plain_c(tmp_path):
 
 def test_abi_version_and_error_channel():
     lib = capi.load()
-    assert lib.fimex_amd_abi_version() == 130
+    assert lib.fimex_amd_abi_version() == 131
     assert isinstance(lib.fimex_amd_last_error(), bytes)
 
 

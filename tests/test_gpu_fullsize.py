@@ -253,6 +253,20 @@ def test_library_placed_output_batch(fa, c2):
     plan.apply_device(d_in.data_ptr(), nz, out.data_ptr(), st)
     torch.cuda.synchronize()
     assert bool(((out.view(torch.int32) == plain.view(torch.int32)) | (out.isnan() & plain.isnan())).all())
+    # the source batch from the library: whole allocations tried, the kept one zero-filled; the same results out of it
+    src = plan.alloc_source_batch(nz, candidates=3, stream=st)
+    si = src.info
+    assert si["positions"] == 3 and len(si["msAtPosition"]) == 3 and si["msAtPosition"][si["chosen"]] == min(si["msAtPosition"])
+    assert si["bytes"] == nz * wl.inX * wl.inY * 4 == si["bytesHeld"] and si["bytesProbed"] >= 3 * si["bytes"]
+    t_src = src.as_tensor()
+    assert t_src.shape == (nz, wl.inY, wl.inX) and not bool(t_src.any())
+    t_src.copy_(d_in)
+    out.fill_(-1.0)
+    plan.apply_device(t_src.data_ptr(), nz, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool(((out.view(torch.int32) == plain.view(torch.int32)) | (out.isnan() & plain.isnan())).all())
+    del t_src
+    src.close()
     one = plan.alloc_batch(0, nz, positions=1, stream=st)  # plain allocation: nothing timed, no source needed
     assert one.info["positions"] == 1 and one.info["msAtPosition"] == []
     one.as_tensor().zero_()

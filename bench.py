@@ -21,9 +21,9 @@ for bit with the CPU oracle, and EVERY slice of it with the same batch regridded
 (fimex_amd_regrid_apply_gather_device) into a second buffer; a mismatch makes the run fail.
 
 Both batches are allocated by the library: the source batch (fimex_amd_regrid_source_batch_alloc_device: --source-candidates whole
-allocations timed with the plan's launch, the fastest kept) and the output batch (fimex_amd_regrid_batch_alloc_device: tried at
---placements windows of one reserved range, the fastest stays, the others' memory goes back to the driver); what plain
-allocations would have got (the first candidate / window) and the cost of the probing are reported in config.source_placement and
+allocations timed with the plan's launch, the fastest kept) and the output batch (fimex_amd_regrid_batch_alloc_device: --placements
+whole allocations, the source batch regridded into each, the fastest kept, the others freed); what plain allocations would have
+got (the first candidate) and the cost of the probing are reported in config.source_placement and
 config.output_placement.  --placements 1 = plain allocations for both.
 """
 import argparse
@@ -309,17 +309,14 @@ def main():
     d_full = torch.empty((nz_total, wl.outY, wl.outX), dtype=torch.float32, device="cuda") if (strong and rank == 0 and dist_on) else None
     d_out = d_full[first:last] if d_full is not None else torch.empty((nz, wl.outY, wl.outX), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    # Where the output batch lies in device memory moves this launch by several per cent (same kernel, same traffic,
-    # per-channel request counts identical; profiles/calib/r03_placement_pmc_*.json).  The allocation is therefore a service of the
-    # library: fimex_amd_regrid_batch_alloc_device maps the batch at --placements windows of one reserved range, times the plan's
-    # apply on this source batch in each, keeps the fastest and returns the other windows' memory.  The time at the first
-    # window -- what a plain allocation would have got -- and the cost of the probing are reported beside the metric.
+    # Which allocation the output batch lies in moves this launch too (same kernel, same traffic, per-channel request
+    # counts identical; profiles/calib/r03_placement_pmc_*.json), so that allocation is a service of the library as well:
+    # fimex_amd_regrid_batch_alloc_device makes --placements whole allocations, times the plan's apply on this source batch into
+    # each, keeps the fastest and frees the others.  The time with the first candidate -- what a plain allocation would have got --
+    # and the cost of the probing are reported beside the metric.
     placement = None
     batch = None
-    # (strong scaling over several GPUs: every rank's block is a send buffer of the overlapped write-back; those stay plain
-    # torch allocations on every rank -- the library's batches are mapped through HIP's virtual memory management, and what
-    # RCCL does with such buffers as peer-to-peer sources could not be tried on the one-GPU boxes this was developed on)
-    if args.placements > 1 and d_full is None and not (strong and dist_on):
+    if args.placements > 1 and d_full is None:
         del d_out
         torch.cuda.empty_cache()
         try:
@@ -330,12 +327,12 @@ def main():
     if batch is not None:
         d_out = batch.as_tensor()
         bi = batch.info
-        placement = {"by": "fimex_amd_regrid_batch_alloc_device", "positions": bi["positions"], "step_MiB": bi["stepBytes"] // (1 << 20),
+        placement = {"by": "fimex_amd_regrid_batch_alloc_device", "positions": bi["positions"],
                      "chosen": bi["chosen"], "ms_at_each": bi["msAtPosition"],
                      "ms_at_first_position": bi["msAtPosition"][0] if bi["msAtPosition"] else None,
-                     "bytes_mapped_while_probing": bi["bytesProbed"], "bytes_held_afterwards": bi["bytesHeld"], "batch_bytes": bi["bytes"],
-                     "other_windows_returned": bool(bi["trimmed"]), "probe_seconds": bi["probeSeconds"],
-                     "note": "default workgroup shape, median of 3 launches per window, before the shape tuning"}
+                     "bytes_allocated_while_probing": bi["bytesProbed"], "bytes_held_afterwards": bi["bytesHeld"], "batch_bytes": bi["bytes"],
+                     "probe_seconds": bi["probeSeconds"],
+                     "note": "whole allocations, default workgroup shape, median of 3 launches each, before the shape tuning"}
 
     # the plan's two workgroup shapes (identical results) timed on this device and this batch, the faster kept: part of the product
     # (fimex_amd_regrid_plan_tune_device), done once per plan like the plan build and outside the timed steps
@@ -513,8 +510,7 @@ def main():
 def measure_weak_write_back(torch, dist, sharding, args, plan, stream, d_in, d_out, d_full, nz, nz_total, first, in_layer, out_layer, world, rank):
     """weak scaling: RCCL gather of every rank's finished slices to rank 0 over xGMI, after the regrid, outside the metric
     (gloo rehearsal: point-to-point on host copies; the measured path is RCCL on device buffers)."""
-    # (sent from a plain torch allocation: see the note on library-placed batches in main; the copy is made before the clock starts)
-    src = d_out.clone() if args.backend == "nccl" else d_out.cpu()
+    src = d_out if args.backend == "nccl" else d_out.cpu()
     dist.barrier()
     torch.cuda.synchronize()
     tg = time.perf_counter()

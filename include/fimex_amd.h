@@ -175,43 +175,39 @@ int fimex_amd_regrid_plan_tune_device(fimex_amd_regrid_plan* plan, const float* 
  */
 int fimex_amd_regrid_apply_gather_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, float* d_out, void* stream);
 
-/* --------------------------------------- output batches placed by the library */
+/* ------------------------------ source and output batches placed by the library */
 /**
- * The reference allocates the result of every interpolateValues call itself (src/CachedInterpolation.cc:123).  A caller that
- * keeps its slices in device memory allocates the output batch [nz][outY][outX] once -- and where that batch lies in device
- * memory moves the apply launch by several per cent.  This call allocates the batch for the caller: it maps it at
- * `positions` windows (704 MiB apart) of one reserved address range, regrids the caller's source batch d_in into each window a
- * few times with the plan's apply launch, keeps the fastest window and returns the physical memory of all others to the driver
- * (HIP virtual memory management; where that is not available the whole range stays allocated, see bytesHeld).
- * positions == 1: a plain allocation, nothing is timed (d_in may be NULL).  Fewer windows are tried when device memory is short.
- * Synchronises the stream.  The batch holds the regridded slices of d_in afterwards only by accident: apply again.
+ * The reference allocates the result of every interpolateValues call itself (src/CachedInterpolation.cc:123) and receives its input
+ * from the reader.  A caller that keeps its slices in device memory allocates the source batch [nz][inY][inX] and the output batch
+ * [nz][outY][outX] once -- and which allocation they lie in moves the apply launch by several per cent (the source's
+ * by 4-5 %, the output's by 1-3 %).  These two calls allocate the batches for the caller: `candidates` whole allocations are made and
+ * held at once, the plan's apply launch is timed with each in its role (median of three launches), the fastest is kept and the others
+ * are freed before the call returns.
+ *   fimex_amd_regrid_source_batch_alloc_device  the buffer the caller's reader fills: every candidate is zero-filled and regridded
+ *                                               into a scratch output; the kept one holds zeros.  Allocate this one first.
+ *   fimex_amd_regrid_batch_alloc_device         the output batch: the caller's source batch d_in is regridded into every candidate
+ *                                               (the batch holds the regridded slices of d_in afterwards only by accident).
+ * candidates == 1: a plain allocation, nothing is timed (d_in may be NULL).  Fewer candidates are tried when device memory is short.
+ * Both synchronise the stream.
  */
 #define FIMEX_AMD_BATCH_MAX_POSITIONS 16
 typedef struct fimex_amd_batch fimex_amd_batch;
 typedef struct fimex_amd_batch_info {
-    void* d_data;        /* the batch: nz*outX*outY floats in device memory */
-    size_t bytes;        /* nz*outX*outY*4 */
-    size_t bytesProbed;  /* device memory mapped while the windows were tried */
-    size_t bytesHeld;    /* device memory behind this batch after the call (bytes rounded up to 32 MiB when trimmed) */
-    size_t stepBytes;    /* distance between two windows */
-    int positions;       /* windows tried */
-    int chosen;          /* the window that was kept */
-    int trimmed;         /* 1: the other windows' memory was returned */
-    float msAtPosition[FIMEX_AMD_BATCH_MAX_POSITIONS];  /* median time of the apply launch with the output in each window */
+    void* d_data;        /* the batch in device memory (plain hipMalloc memory) */
+    size_t bytes;        /* of the batch */
+    size_t bytesProbed;  /* device memory allocated while the candidates were tried */
+    size_t bytesHeld;    /* device memory behind this batch after the call (== bytes) */
+    size_t stepBytes;    /* 0 (candidates are separate allocations) */
+    int positions;       /* candidates tried */
+    int chosen;          /* the one that was kept */
+    int trimmed;         /* 1: the other candidates were freed */
+    float msAtPosition[FIMEX_AMD_BATCH_MAX_POSITIONS];  /* median time of the apply launch with each candidate */
     double probeSeconds; /* wall time of the whole call */
 } fimex_amd_batch_info;
-int fimex_amd_regrid_batch_alloc_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, int positions, void* stream,
-                                        fimex_amd_batch** batch);
-/**
- * The same service for the SOURCE batch [nz][inY][inX] of a resident pipeline, the buffer its reader fills: which allocation the source
- * slices lie in moves the apply launch by 4-5 % (more than the output's).  `candidates` whole allocations are made,
- * zero-filled and timed with the plan's apply launch into a scratch output; the fastest is kept (filled with zeros), the others and the
- * scratch are freed before the call returns.  In the info: positions = candidates, msAtPosition[] per candidate, bytesProbed = what was
- * allocated meanwhile, bytesHeld = the batch.  candidates == 1: a plain allocation.  Allocate the source batch first, then the
- * output batch with it as d_in.  Synchronises the stream.
- */
 int fimex_amd_regrid_source_batch_alloc_device(const fimex_amd_regrid_plan* plan, size_t nz, int candidates, void* stream,
                                                fimex_amd_batch** batch);
+int fimex_amd_regrid_batch_alloc_device(const fimex_amd_regrid_plan* plan, const float* d_in, size_t nz, int candidates, void* stream,
+                                        fimex_amd_batch** batch);
 int fimex_amd_batch_get_info(const fimex_amd_batch* batch, fimex_amd_batch_info* info);
 int fimex_amd_batch_free(fimex_amd_batch* batch);
 

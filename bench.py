@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-slice, copy and gather measurements")
     ap.add_argument("--placements", type=int, default=8,
                     help="windows the library tries for the output batch (fimex_amd_regrid_batch_alloc_device; 1 = plain allocation)")
-    ap.add_argument("--source-candidates", type=int, default=4,
+    ap.add_argument("--source-candidates", type=int, default=6,
                     help="allocations the library tries for the source batch (fimex_amd_regrid_source_batch_alloc_device; 1 = plain allocation)")
     ap.add_argument("--workload", default="default", choices=["default", "one_percent"],
                     help="target axes: round 1's (10.9 %% of the target cells undefined) or the ~1 %% variant of SURVEY 8d")

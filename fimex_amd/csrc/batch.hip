@@ -56,8 +56,18 @@ fimex_amd_batch* alloc_best(const fimex_amd_regrid_plan& plan, size_t bytes, siz
             if (c != keep && cand[(size_t)c]) { (void)hipFree(cand[(size_t)c]); cand[(size_t)c] = nullptr; }
     };
     try {
+        // tuning build: BATCH_CONTIGUOUS 1 = every candidate, 2 = every other one physically contiguous (hipDeviceMallocContiguous).
+        // Measured (profiles/calib/r03_bench_contiguous_candidates.jsonl): contiguous OUTPUT batches are the slow kind throughout
+        // (2.33 against 2.26-2.28 ms for their plain neighbours), contiguous source batches are fast or slow like plain ones.
+        const int contiguous = tuning("BATCH_CONTIGUOUS", 0);
         for (int c = 0; c < candidates; ++c) {
-            FA_HIP(hipMalloc(&cand[(size_t)c], bytes));
+            if (contiguous == 1 || (contiguous == 2 && (c & 1))) {
+                if (hipExtMallocWithFlags(&cand[(size_t)c], bytes, hipDeviceMallocContiguous) != hipSuccess) {
+                    (void)hipGetLastError();
+                    cand[(size_t)c] = nullptr;
+                }
+            }
+            if (!cand[(size_t)c]) FA_HIP(hipMalloc(&cand[(size_t)c], bytes));
             if (zeroFill) FA_HIP(hipMemsetAsync(cand[(size_t)c], 0, bytes, stream));
         }
         info.bytesProbed = (size_t)candidates * bytes + (candidates > 1 ? extraBytes : 0);

@@ -1033,6 +1033,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(f + (size_t)(y0 - 1) * nx, 0, (nrow + 2) * nx * 4u, 0x00020000);
     const uint32_t kOob = 0xFFFFFFFFu;
     const bool prof = kTuningBuild && mg.experiment == 4 && mg.prof != nullptr;
+    const bool earlyPrefetch = !(kTuningBuild && mg.experiment == 5);  // tuning build, FILL_EXPERIMENT=5: the prefetch after the waits (round 2's order)
     unsigned long long tWait = 0, tFlush = 0;
     // Every W-th boundary (band W-1 -> W, 2W-1 -> 2W, ...) goes through global memory: in one workgroup the wave of band b + 1
     // is still busy with band b + 1 - W there (a bounded LDS window would close a cycle of waiting waves on wide grids), with
@@ -1209,6 +1210,9 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
             }
             flush_read(c - 1);       // results of the chunk just finished: ring -> registers
             commit_chunk(c + 1);     // loaded one event ago, into the ring slot the flush has just read
+            // The prefetch of chunk c + 2 goes out as soon as its registers are free -- before the waits on the neighbouring bands
+            // below, which may take as long as the 16 steps do: the loads are what the next event waits for.
+            if (earlyPrefetch) load_chunk(c + 2);
             // publish how far the last row has got, and do not run more than the hand-off window ahead of the band below
             if (xpc > L && !outGlobal) {
                 if (lane == 0)
@@ -1227,7 +1231,7 @@ __device__ void fill2d_band(float* __restrict__ f, const uint32_t* __restrict__ 
                 }
             }
             if (!fromGlobal) take_above(xpc, upCur);
-            load_chunk(c + 2);       // consumed at the next event
+            if (!earlyPrefetch) load_chunk(c + 2);       // consumed at the next event
             flush_store(c - 1);      // registers -> global, behind the loads (never waited for)
         }
         if (prof) { const unsigned long long t = clock64(); tEvents += t - tMark; tMark = t; }
@@ -1894,6 +1898,7 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
             }
             flush_read(c - 1);
             commit_chunk(c + 1);
+            load_chunk(c + 2);  // as soon as its registers are free, before the waits on the neighbouring bands (see fill2d_band)
             if (xpc > L && !outGlobal) {
                 if (lane == 0)
                     lds_publish(&hand.produced[slotOut], hand_tag(b, xpc - L));
@@ -1909,7 +1914,6 @@ __device__ void creep_band(float* __restrict__ f, const uint32_t* __restrict__ m
                 }
             }
             if (!fromGlobal) take_above(xpc, upCur, upWCur);
-            load_chunk(c + 2);
             flush_store(c - 1);
         }
         const uint32_t xp0 = max(xpc, 1u), xp1 = min(xpc + kCreepCh - 1, xpEnd);

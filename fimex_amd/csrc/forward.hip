@@ -70,11 +70,11 @@ __device__ __forceinline__ bool keep(float v) { return UNDEF || !isnan(v); }
 template <int KIND, bool UNDEF, int ZC>
 __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint32_t e, uint32_t i0, const float* src, const size_t (&koff)[ZC], float (&r)[ZC])
 {
-    float acc[ZC], second[ZC];
+    float acc[ZC];
     uint32_t cnt[ZC];
     bool anyNan[ZC];
 #pragma unroll
-    for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; second[k] = 0.f; cnt[k] = 0; anyNan[k] = false; }
+    for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; cnt[k] = 0; anyNan[k] = false; }
     for (uint32_t j = b; j < e; ++j) {
         const uint32_t i = (j == b) ? i0 : a.src[j];
         float v[ZC];
@@ -86,7 +86,10 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
                 if (KIND == 0 || KIND == 1) acc[k] = acc[k] + v[k];                        // std::accumulate(.., 0.f)
                 else if (KIND == 3) { if (cnt[k] == 0 || acc[k] < v[k]) acc[k] = v[k]; }   // std::max_element
                 else if (KIND == 4) { if (cnt[k] == 0 || v[k] < acc[k]) acc[k] = v[k]; }   // std::min_element
-                else { if (cnt[k] == 0) acc[k] = v[k]; else second[k] = v[k]; if (isnan(v[k])) anyNan[k] = true; }
+                else {  // median of at most two: the larger one, the second where they compare equal -- a running form of it
+                    if (UNDEF && isnan(v[k])) anyNan[k] = true;
+                    if (cnt[k] == 0 || !(acc[k] > v[k])) acc[k] = v[k];
+                }
                 cnt[k]++;
             }
         }
@@ -98,7 +101,7 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
             if (KIND == 1) r[k] = acc[k] / (float)cnt[k];  // aggrMean: sum / size()
             else if (KIND == 5) {
                 // a NaN inside an "undef" bucket: see median_by_rank
-                if (!(UNDEF && anyNan[k])) r[k] = (cnt[k] == 1 || acc[k] > second[k]) ? acc[k] : second[k];
+                if (!(UNDEF && anyNan[k])) r[k] = acc[k];
             } else r[k] = acc[k];
         }
     }
@@ -378,7 +381,11 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     case Aggregate::Median:
         // buckets of at most two cells: eight slices in flight, no rank counting; longer ones are ranked slice by slice by the same kernel
         // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
-        if (plan.info.maxBucket > 2 || a.rankAll != 0) {
+        if (plan.info.maxBucket <= 1 && a.rankAll == 0) {
+            // no bucket holds more than one cell (a source grid coarser than the target, configs[3]): the median of one value is
+            // the value, which is what the max kernel returns for it bit for bit -- without the median's per-slice state
+            u ? launch_kind<3, true>(a, gridLane, false, stream) : launch_kind<3, false>(a, gridLane, false, stream);
+        } else if (plan.info.maxBucket > 2 || a.rankAll != 0) {
             if (u) forward_apply_lane<5, true, kLaneZc, true><<<gridLane, kBlock, 0, stream>>>(a);
             else forward_apply_lane<5, false, kLaneZc, true><<<gridLane, kBlock, 0, stream>>>(a);
         } else if (tuning("FWD_MEDIAN_ZC", 8) == 4) {

@@ -22,6 +22,8 @@
 // the same type and order as the reference, so results are bit-identical to the CPU path.
 #include "plan.hpp"
 
+#include <type_traits>
+
 #include <algorithm>
 #include "typed_convert.hpp"
 
@@ -285,8 +287,8 @@ __global__ void __launch_bounds__(kBlock) bilinear_apply(ApplyArgs a, const uint
     }
 }
 
-// Fewer slices than the staged kernels need (nz < 4): one time step of a variable without levels, the reference's call pattern
-// for surface fields (src/CDMInterpolator.cc:251-259).  There is no slice loop to keep loads in flight across, and a lane with
+// ONE slice per call: one time step of a variable without levels, the reference's call pattern for surface fields
+// (src/CDMInterpolator.cc:251-259).  There is no slice loop to keep loads in flight across, and a lane with
 // one output cell spends its life in two dependent round trips to memory (plan entry, then stencil).  Here a lane takes CELLS
 // output cells of a 64 x (4 * CELLS) tile (rows y, y + 4, ...): the plan entries of all of them are loaded first, then all
 // their stencil values -- four times the bytes in flight per lane; border and undefined cells are computed by selection
@@ -694,14 +696,23 @@ void launch_backward_gather(const fimex_amd_regrid_plan& plan, const float* d_in
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
     dim3 grid;
     const ApplyArgs a = make_args(plan, d_in, nz, d_out, grid);
-    if (nz < staged_min_nz() && plan.kind != PlanKind::Bicubic && tuning("FEW", 1) != 0) {
-        // one or a few slices: four output cells per lane (apply_few)
-        constexpr int kCells = 4;
-        const uint32_t tilesX = (uint32_t)ceil_div(plan.outX, (size_t)64), tilesY = (uint32_t)ceil_div(plan.outY, (size_t)(4 * kCells));
-        const uint32_t nTiles = tilesX * tilesY, perXcd = (uint32_t)ceil_div(nTiles, kXcds);
-        const dim3 g(perXcd * kXcds);
-        if (plan.kind == PlanKind::Nearest) apply_few<1, kCells><<<g, kBlock, 0, stream>>>(a, plan.pos.get(), nullptr, nullptr, tilesX, nTiles, perXcd);
-        else apply_few<2, kCells><<<g, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get(), tilesX, nTiles, perXcd);
+    if (nz == 1 && plan.kind != PlanKind::Bicubic && tuning("FEW", 1) != 0) {
+        // one slice: several output cells per lane (apply_few).  Measured cold, a different slice pair every call
+        // (profiles/r03_sweep_few_cells*.log): 2 / 4 / 8 cells per lane 24.4 / 25.5 / 28.0 us against 29.4 us for one cell per lane;
+        // with two or three slices the kernels below, which keep the slices of a cell in flight together, are ahead again
+        // (40.4 against 42 us, 52 against 59 us).
+        const int cells = tuning("FEW_CELLS", 2);
+        auto go = [&](auto cellsTag) {
+            constexpr int kCells = decltype(cellsTag)::value;
+            const uint32_t tilesX = (uint32_t)ceil_div(plan.outX, (size_t)64), tilesY = (uint32_t)ceil_div(plan.outY, (size_t)(4 * kCells));
+            const uint32_t nTiles = tilesX * tilesY, perXcd = (uint32_t)ceil_div(nTiles, kXcds);
+            const dim3 g(perXcd * kXcds);
+            if (plan.kind == PlanKind::Nearest) apply_few<1, kCells><<<g, kBlock, 0, stream>>>(a, plan.pos.get(), nullptr, nullptr, tilesX, nTiles, perXcd);
+            else apply_few<2, kCells><<<g, kBlock, 0, stream>>>(a, plan.pos.get(), plan.xf.get(), plan.yf.get(), tilesX, nTiles, perXcd);
+        };
+        if (cells == 2) go(std::integral_constant<int, 2>());
+        else if (cells == 8) go(std::integral_constant<int, 8>());
+        else go(std::integral_constant<int, 4>());
         FA_HIP(hipGetLastError());
         return;
     }

@@ -67,7 +67,8 @@ __device__ __forceinline__ bool keep(float v) { return UNDEF || !isnan(v); }
 // which is what counting "less, or equal and earlier" picks, src/CachedForwardInterpolation.cc:49-53).
 // i0: the bucket's first source cell, loaded once per lane outside the slice loop (most buckets hold one cell: no dependent
 // index load per slice group is left).
-template <int KIND, bool UNDEF, int ZC>
+// AHEAD: source cells whose values are requested before the first of them is added (1: none ahead -- plans whose buckets are short)
+template <int KIND, bool UNDEF, int ZC, int AHEAD>
 __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint32_t e, uint32_t i0, const float* src, const size_t (&koff)[ZC], float (&r)[ZC])
 {
     float acc[ZC];
@@ -75,11 +76,7 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
     bool anyNan[ZC];
 #pragma unroll
     for (int k = 0; k < ZC; ++k) { acc[k] = 0.f; cnt[k] = 0; anyNan[k] = false; }
-    for (uint32_t j = b; j < e; ++j) {
-        const uint32_t i = (j == b) ? i0 : a.src[j];
-        float v[ZC];
-#pragma unroll
-        for (int k = 0; k < ZC; ++k) v[k] = src[koff[k] + i];
+    auto take = [&](const float (&v)[ZC]) __attribute__((always_inline)) {  // one source cell of the bucket, all ZC slices, in scan order
 #pragma unroll
         for (int k = 0; k < ZC; ++k) {
             if (keep<UNDEF>(v[k])) {
@@ -93,6 +90,32 @@ __device__ __forceinline__ void reduce_bucket(const FwdArgs& a, uint32_t b, uint
                 cnt[k]++;
             }
         }
+    };
+    uint32_t j = b;
+    // long buckets (a source finer than the target): the values of AHEAD cells are requested before the first is added -- the
+    // additions stay in scan order, but a lane no longer waits a memory round trip per cell (0.1-degree global -> 1-degree global,
+    // 100 cells per bucket, 100 slices: 3.87 ms without, 1.74 ms with 4, 1.38 ms with 8 cells ahead; the registers this takes cost
+    // the sparse plans of configs[3] 13 %, hence the variant without)
+    constexpr int kAhead = AHEAD;
+    if constexpr (AHEAD > 1)
+    for (; j + kAhead <= e; j += kAhead) {
+        uint32_t i[kAhead];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) i[q] = (q == 0 && j == b) ? i0 : a.src[j + q];
+        float v[kAhead][ZC];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q)
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) v[q][k] = src[koff[k] + i[q]];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) take(v[q]);
+    }
+    for (; j < e; ++j) {
+        const uint32_t i = (j == b) ? i0 : a.src[j];
+        float v[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) v[k] = src[koff[k] + i];
+        take(v);
     }
 #pragma unroll
     for (int k = 0; k < ZC; ++k) {
@@ -143,7 +166,7 @@ __device__ __forceinline__ float median_by_rank(const FwdArgs& a, uint32_t b, ui
 // cells (blocks of 256 consecutive cells), so that a source line -- whose cells map to neighbouring targets in several target
 // rows -- is fetched into ONE L2 instead of into all eight (configs[3]: 1.85 GB -> about 1.1 GB of fabric traffic per 100 slices).
 // RANK (median only): some bucket of the plan holds more than two cells; without it the rank-counting path is not compiled in
-template <int KIND, bool UNDEF, int ZC, bool RANK = false>
+template <int KIND, bool UNDEF, int ZC, bool RANK = false, int AHEAD = 1>
 __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 {
     const uint32_t perXcd = gridDim.x / kXcds;  // the grid holds 8 * perXcd workgroups per z chunk
@@ -168,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) forward_apply_lane(FwdArgs a)
 #pragma unroll
         for (int k = 0; k < ZC; ++k) koff[k] = (size_t)min((uint32_t)k, z1 - 1 - z) * a.inLayer;
         float r[ZC];
-        reduce_bucket<KIND, UNDEF, ZC>(a, b, e, i0, src, koff, r);
+        reduce_bucket<KIND, UNDEF, ZC, AHEAD>(a, b, e, i0, src, koff, r);
 #pragma unroll
         for (int k = 0; k < ZC; ++k)
             if (z + k < z1) __builtin_nontemporal_store(r[k], a.out + (size_t)(z + k) * a.nOut + t);
@@ -226,12 +249,23 @@ __global__ void __launch_bounds__(kBlock) forward_apply_wave(FwdArgs a)
                 }
                 // NaNs after the first position never win a "<" comparison: neutralise them
                 const bool usableV = valid && !isnan(v);
+                // std::max_element / min_element return the FIRST of the elements that compare equal to the extremum: of +0.0 and
+                // -0.0 the one that comes first in the bucket.  The shuffle reduction finds the value, the lowest lane that holds it
+                // supplies the bits.
                 if (KIND == 3) {
                     const float m = wave_max(usableV ? v : -INFINITY);
-                    if (__ballot(usableV)) acc = (cnt == 0 || acc < m) ? m : acc;
+                    const unsigned long long at = __ballot(usableV && v == m);
+                    if (at) {
+                        const float first = __shfl(v, __ffsll((long long)at) - 1, kWave);
+                        acc = (cnt == 0 || acc < first) ? first : acc;
+                    }
                 } else {
                     const float m = wave_min(usableV ? v : INFINITY);
-                    if (__ballot(usableV)) acc = (cnt == 0 || m < acc) ? m : acc;
+                    const unsigned long long at = __ballot(usableV && v == m);
+                    if (at) {
+                        const float first = __shfl(v, __ffsll((long long)at) - 1, kWave);
+                        acc = (cnt == 0 || first < acc) ? first : acc;
+                    }
                 }
             }
             cnt += (uint32_t)__popcll(mask);
@@ -250,12 +284,86 @@ __global__ void __launch_bounds__(kBlock) forward_apply_wave(FwdArgs a)
 
 constexpr int kLaneZc = 8;  // slices a lane reduces together (gathers in flight per lane)
 
+// Median of buckets of up to 64 * Q source cells, one wave per target cell: the bucket's values of one slice sit in Q registers per
+// lane (position q * 64 + lane of the bucket's scan order), every kept value is broadcast once (v_readlane) and every lane counts,
+// for its own values, how many kept values are smaller or equal-and-earlier -- its rank in the order std::nth_element's result
+// follows (src/CachedForwardInterpolation.cc:49-53).  The one value of rank size() / 2 is the median; its lane stores it.
+// n * Q comparisons per lane instead of the n * n loads of median_by_rank: 0.1-degree global -> 1-degree global (100 cells per
+// bucket), 100 slices: 130 ms -> see DESIGN.md 6.
+template <bool UNDEF, int Q>
+__global__ void __launch_bounds__(kBlock) forward_apply_median_wave(FwdArgs a)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= a.nOut) return;  // wave-uniform
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t b = a.offsets[t], n0 = a.offsets[t + 1] - b;
+    if (n0 == 0) {
+        if (lane == 0)
+            for (uint32_t z = z0; z < z1; ++z) a.out[(size_t)z * a.nOut + t] = undefined_f();
+        return;
+    }
+    uint32_t idx[Q];
+    bool has[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const uint32_t p = (uint32_t)q * kWave + lane;
+        has[q] = p < n0;
+        idx[q] = has[q] ? a.src[b + p] : 0u;
+    }
+    for (uint32_t z = z0; z < z1; ++z) {
+        const float* src = a.in + (size_t)z * a.inLayer;
+        float v[Q];
+        bool kept[Q];
+        unsigned long long keptMask[Q];
+        bool nanHere = false;
+        uint32_t n = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            v[q] = has[q] ? src[idx[q]] : 0.f;
+            kept[q] = has[q] && keep<UNDEF>(v[q]);
+            nanHere = nanHere || (has[q] && isnan(v[q]));
+            keptMask[q] = __ballot(kept[q]);
+            n += (uint32_t)__popcll(keptMask[q]);
+        }
+        const bool anyNan = __ballot(nanHere) != 0;
+        float* o = a.out + (size_t)z * a.nOut + t;
+        // a NaN inside an "undef" bucket: the reference's nth_element result is implementation-defined; value + undef = undef is kept
+        if (n == 0 || (UNDEF && anyNan)) {
+            if (lane == 0) *o = undefined_f();
+            continue;
+        }
+        uint32_t rank[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) rank[q] = 0;
+#pragma unroll
+        for (int q2 = 0; q2 < Q; ++q2) {
+            unsigned long long m = keptMask[q2];  // wave-uniform: the loop below runs on the scalar unit
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[q2]), l));
+                const uint32_t pu = (uint32_t)q2 * kWave + (uint32_t)l;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) rank[q] += (u < v[q] || (u == v[q] && pu < (uint32_t)q * kWave + lane)) ? 1u : 0u;
+            }
+        }
+        const uint32_t want = n / 2;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (kept[q] && rank[q] == want) *o = v[q];  // exactly one value of the bucket has this rank
+    }
+}
+
 template <int KIND, bool UNDEF>
-void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, hipStream_t stream)
+void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, bool longBuckets, hipStream_t stream)
 {
     if (wavePath) {
         dim3 g((uint32_t)ceil_div(a.nOut, kBlock / kWave), grid.y, 1);
         forward_apply_wave<KIND, UNDEF><<<g, kBlock, 0, stream>>>(a);
+    } else if (longBuckets) {
+        forward_apply_lane<KIND, UNDEF, kLaneZc, false, 8><<<grid, kBlock, 0, stream>>>(a);
     } else {
         forward_apply_lane<KIND, UNDEF, kLaneZc><<<grid, kBlock, 0, stream>>>(a);
     }
@@ -371,20 +479,34 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
     const size_t nonEmpty = a.nOut - plan.info.undefinedCells;
     const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
     int waveMode = tuning("FWD_WAVE", -1);
-    const bool wavePath = (waveMode < 0) ? (meanBucket >= 32.0) : (waveMode != 0);
+    // wave per bucket only where the targets are too few to fill the chip with lanes (fewer than 64 K (target, z chunk) lanes): a
+    // dense mapping with many targets runs 1.7-1.8 ms through the lane kernels against 6.5 (mean: the ordered fold) and 2.0 ms (max)
+    // through the wave kernels (0.1-degree global -> 1-degree global, 100 cells per bucket, 100 slices)
+    const bool wavePath = (waveMode < 0) ? (meanBucket >= 32.0 && (size_t)a.nOut * chunks < 65536) : (waveMode != 0);
+    const bool longBuckets = meanBucket > 4.0;  // the lane kernels with eight cells of look-ahead
     const bool u = plan.undefAggr;
     switch (plan.aggregate) {
-    case Aggregate::Sum: u ? launch_kind<0, true>(a, gridLane, wavePath, stream) : launch_kind<0, false>(a, gridLane, wavePath, stream); break;
-    case Aggregate::Mean: u ? launch_kind<1, true>(a, gridLane, wavePath, stream) : launch_kind<1, false>(a, gridLane, wavePath, stream); break;
-    case Aggregate::Max: u ? launch_kind<3, true>(a, gridLane, wavePath, stream) : launch_kind<3, false>(a, gridLane, wavePath, stream); break;
-    case Aggregate::Min: u ? launch_kind<4, true>(a, gridLane, wavePath, stream) : launch_kind<4, false>(a, gridLane, wavePath, stream); break;
+    case Aggregate::Sum: u ? launch_kind<0, true>(a, gridLane, wavePath, longBuckets, stream) : launch_kind<0, false>(a, gridLane, wavePath, longBuckets, stream); break;
+    case Aggregate::Mean: u ? launch_kind<1, true>(a, gridLane, wavePath, longBuckets, stream) : launch_kind<1, false>(a, gridLane, wavePath, longBuckets, stream); break;
+    case Aggregate::Max: u ? launch_kind<3, true>(a, gridLane, wavePath, longBuckets, stream) : launch_kind<3, false>(a, gridLane, wavePath, longBuckets, stream); break;
+    case Aggregate::Min: u ? launch_kind<4, true>(a, gridLane, wavePath, longBuckets, stream) : launch_kind<4, false>(a, gridLane, wavePath, longBuckets, stream); break;
     case Aggregate::Median:
         // buckets of at most two cells: eight slices in flight, no rank counting; longer ones are ranked slice by slice by the same kernel
         // (four targets per lane with 16-byte stores were measured as well: 8 % slower on configs[3], the gathers lose parallelism)
         if (plan.info.maxBucket <= 1 && a.rankAll == 0) {
             // no bucket holds more than one cell (a source grid coarser than the target, configs[3]): the median of one value is
             // the value, which is what the max kernel returns for it bit for bit -- without the median's per-slice state
-            u ? launch_kind<3, true>(a, gridLane, false, stream) : launch_kind<3, false>(a, gridLane, false, stream);
+            u ? launch_kind<3, true>(a, gridLane, false, false, stream) : launch_kind<3, false>(a, gridLane, false, false, stream);
+        } else if (a.rankAll == 0 && plan.info.maxBucket > 2 && plan.info.maxBucket <= 256 && meanBucket >= 4.0 && tuning("FWD_MEDIAN_WAVE", 1) != 0) {
+            // medium buckets throughout (a source finer than the target): one wave per target, ranks by broadcast
+            const dim3 g((uint32_t)ceil_div(a.nOut, kBlock / kWave), gridLane.y, 1);
+            if (plan.info.maxBucket <= 128) {
+                if (u) forward_apply_median_wave<true, 2><<<g, kBlock, 0, stream>>>(a);
+                else forward_apply_median_wave<false, 2><<<g, kBlock, 0, stream>>>(a);
+            } else {
+                if (u) forward_apply_median_wave<true, 4><<<g, kBlock, 0, stream>>>(a);
+                else forward_apply_median_wave<false, 4><<<g, kBlock, 0, stream>>>(a);
+            }
         } else if (plan.info.maxBucket > 2 || a.rankAll != 0) {
             if (u) forward_apply_lane<5, true, kLaneZc, true><<<gridLane, kBlock, 0, stream>>>(a);
             else forward_apply_lane<5, false, kLaneZc, true><<<gridLane, kBlock, 0, stream>>>(a);

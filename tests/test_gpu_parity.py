@@ -1060,6 +1060,33 @@ def test_release_caches_between_host_calls(fa):
     assert got.dtype == np.int16
 
 
+@pytest.mark.parametrize("method", [oracle.FWD_MEDIAN, oracle.FWD_UNDEF_MEDIAN, oracle.FWD_MEAN, oracle.FWD_MAX, oracle.FWD_UNDEF_MIN])
+@pytest.mark.parametrize("shape,density", [((240, 200, 40, 30), 1.2), ((240, 200, 40, 30), 7.0), ((300, 256, 64, 48), 3.0)])
+def test_forward_dense_mappings(fa, monkeypatch, method, shape, density, tuning_build):
+    """A source finer than the target (what forward interpolation is for): tens to a couple of hundred source cells per bucket.  The
+    median goes through the wave kernel (ranks by broadcast, two or four registers of bucket values per lane), sums and extrema through
+    the lane kernels with eight cells of look-ahead; NaNs, signed zeros and many equal values in the data.  Same bits as the oracle,
+    and as the rank-counting median of the lane kernel."""
+    inX, inY, outX, outY = shape
+    nz = 5
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=23, density=density, special=False)
+    f = cases.field(nz, inY, inX, seed=60 + method, nan_frac=0.03)
+    f[:, ::3, ::2] = np.float32(0.0)
+    f[:, 1::3, 1::2] = np.float32(-0.0)
+    f[:, 2::7, ::3] = np.float32(281.5)   # many equal values inside a bucket: ties are broken by position
+    want = oracle.forward_interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    info = plan.info()
+    assert 8 < info["maxBucket"] <= 256, info["maxBucket"]
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(want[~np.isnan(want)]))
+    monkeypatch.setenv("FIMEX_AMD_FWD_MEDIAN_WAVE", "0")
+    monkeypatch.setenv("FIMEX_AMD_FWD_WAVE", "1")
+    other = plan.apply_host(f)   # the other kernels of the same method: rank counting per lane, wave per bucket
+    assert cases.same(other, want), cases.describe_mismatch(other, want)
+
+
 @pytest.mark.parametrize("method", FORWARD)
 @pytest.mark.parametrize("shape,density", [((150, 120, 64, 50), 0.08), ((150, 120, 63, 51), 0.08), ((300, 200, 100, 80), 0.5), ((200, 150, 40, 36), 2.5)])
 def test_forward_sparse_mappings_and_short_median(fa, monkeypatch, method, shape, density, tuning_build):

@@ -20,7 +20,7 @@ TUNING_LIB = os.path.join(HERE, "libfimex_amd_tuning.so")  # the same sources wi
 HOSTLIB = os.path.join(HERE, "libfimex_amd_host.so")
 HOSTCLI = os.path.join(HERE, "host_cli")  # executable of the C++ host mirror (listed in .gitignore by name)
 
-DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "staged2.hip", "forward.hip", "vector.hip", "convert.hip", "fill.hip", "projection.hip", "coordsearch.hip", "hostpipe.hip", "batch.hip"]
+DEVICE_SOURCES = ["capi.hip", "regrid.hip", "staged.hip", "staged2.hip", "forward.hip", "forward_tiled.hip", "vector.hip", "convert.hip", "fill.hip", "projection.hip", "coordsearch.hip", "hostpipe.hip", "batch.hip"]
 
 # -ffp-contract=off: the kernels reproduce the reference's IEEE arithmetic operation by operation
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

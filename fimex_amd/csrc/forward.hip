@@ -447,12 +447,14 @@ void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const d
     plan.info.undefinedCells = empty;
     plan.info.maxBucket = maxBucket;
     plan.info.mappedSourceCells = mapped;
+    build_forward_tiles(plan, stream);  // dense mappings: the LDS-staged form (forward_tiled.hip)
 }
 
 void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
 {
     if (nz == 0) return;
     FA_REQUIRE(nz <= 0xFFFFFFFFu, "too many slices");
+    if (launch_forward_tiled(plan, d_in, nz, d_out, stream)) return;  // dense mappings, all aggregates but the median
     FwdArgs a{};
     a.in = d_in;
     a.out = d_out;

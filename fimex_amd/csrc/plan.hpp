@@ -65,6 +65,22 @@ struct Staged2Plan {
     DeviceArray<uint32_t> chunkOff;  // source cell offset of every chunk inside a slice
     DeviceArray<uint32_t> ldsA, ldsB;
 };
+
+// forward_tiled.hip: the LDS-staged form of a forward plan whose buckets are long (tiles of 64 targets, one wave each)
+struct ForwardTile {
+    uint32_t chunkBase;  // first entry of the tile in chunkOff
+    uint32_t nChunks;    // ~0u: the tile's buckets are spread too far for LDS, it reads from memory
+    uint32_t stepBase;   // first entry of the tile in steps
+    uint32_t maxLen;     // longest bucket of the tile; 0: every target of the tile is empty
+};
+struct ForwardTiles {
+    bool valid = false;
+    uint32_t tw = 0, th = 0, tilesX = 0, nTiles = 0, slotChunks = 0, tableBytes = 0;
+    size_t stagedTiles = 0, directTiles = 0, stagedChunks = 0;
+    DeviceArray<ForwardTile> tiles;
+    DeviceArray<uint32_t> chunkOff;      // source cell index of every 16-byte chunk a tile stages, row by row
+    DeviceArray<unsigned short> steps;   // LDS position of every cell of every bucket, in the order the lanes of a tile walk them
+};
 }  // namespace fimex_amd
 
 struct fimex_amd_regrid_plan {
@@ -101,6 +117,7 @@ struct fimex_amd_regrid_plan {
     fimex_amd::Aggregate aggregate = fimex_amd::Aggregate::Sum;
     bool undefAggr = false;
     fimex_amd::DeviceArray<uint32_t> offsets, src;
+    fimex_amd::ForwardTiles fwdTiles;
 
     fimex_amd_plan_info info{};
 };
@@ -134,6 +151,10 @@ bool launch_staged2_apply_typed(const fimex_amd_regrid_plan& plan, const void* d
 // forward.hip
 void build_forward_plan(fimex_amd_regrid_plan& plan, const double* d_px, const double* d_py, hipStream_t stream);
 void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+
+// forward_tiled.hip
+void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream);
+bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
 
 // vector.hip
 void build_vector_plan(fimex_amd_vector_plan& plan, const double* h_matrix);

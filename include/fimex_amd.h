@@ -134,8 +134,8 @@ typedef struct fimex_amd_plan_info {
     size_t borderCells;        /* backward bilinear: cells on a border branch (interpolation.c:903-948) */
     size_t maxBucket;          /* forward: largest bucket (source cells per target) */
     size_t mappedSourceCells;  /* forward: source cells that fall inside the target grid */
-    size_t stagedCells;        /* backward, LDS-staged kernel: source cells streamed per slice over all tiles (0: gather kernel) */
-    size_t tileW, tileH;       /* LDS-staged kernel: output cells per tile */
+    size_t stagedCells;        /* LDS-staged kernels (backward; forward plans with long buckets): source cells streamed per slice over all tiles (0: gather / lane kernels) */
+    size_t tileW, tileH;       /* LDS-staged kernels: output cells per tile */
 } fimex_amd_plan_info;
 int fimex_amd_regrid_plan_info(const fimex_amd_regrid_plan* plan, fimex_amd_plan_info* info);
 

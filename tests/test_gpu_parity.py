@@ -1087,6 +1087,50 @@ def test_forward_dense_mappings(fa, monkeypatch, method, shape, density, tuning_
     assert cases.same(other, want), cases.describe_mismatch(other, want)
 
 
+@pytest.mark.parametrize("method", [oracle.FWD_SUM, oracle.FWD_MEAN, oracle.FWD_UNDEF_MEAN, oracle.FWD_MAX, oracle.FWD_UNDEF_MAX, oracle.FWD_MIN, oracle.FWD_UNDEF_SUM, oracle.FWD_MEDIAN])
+@pytest.mark.parametrize("shape,density,special", [((400, 300, 37, 29), 1.5, False), ((300, 200, 50, 33), 1.0, True), ((512, 200, 130, 13), 1.6, False),
+                                                    ((333, 377, 32, 80), 1.3, True), ((1203, 60, 60, 9), 1.8, False)])
+def test_forward_tiled_mappings(fa, monkeypatch, method, shape, density, special, tuning_build):
+    """Long buckets (mean lengths 20 to 135 here): the LDS-staged forward kernel (forward_tiled.hip) -- tiles of 64 targets, the source rows of
+    a tile's buckets streamed through LDS, the lanes walking their buckets through the step table in the reference's scan order.
+    Rotated, wavy mappings, target grids that are no multiple of the tile, source rows of odd length (chunks are cut on multiples
+    of four cells of the slice, not of the row), NaNs / signed zeros / equal values, `special`: source cells thrown to the corners
+    and edges of the target (buckets whose cells lie far apart: tiles that cannot be staged read from memory).  Same bits as the
+    oracle with either tile shape, one or two slices in LDS, and as the lane kernels."""
+    inX, inY, outX, outY = shape
+    nz = 7
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=31, density=density, special=special)
+    f = cases.field(nz, inY, inX, seed=70 + method, nan_frac=0.02)
+    f[:, ::3, ::2] = np.float32(0.0)
+    f[:, 1::3, 1::2] = np.float32(-0.0)
+    f[:, 2::7, ::3] = np.float32(281.5)
+    f[:, 5::11, :] = np.nan  # whole rows undefined: buckets that start with NaNs
+    want = oracle.forward_interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    info = plan.info()
+    median = method == oracle.FWD_MEDIAN  # ranks in registers, one wave per target: no tiled form
+    assert median or (info["stagedCells"] > 0 and info["tileW"] * info["tileH"] == 64), info
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(want[~np.isnan(want)]))
+    for slots in ("1", "2"):
+        monkeypatch.setenv("FIMEX_AMD_FWD_TILED_SLOTS", slots)
+        other = plan.apply_host(f[:3])
+        assert cases.same(other, want[:3]), (slots, cases.describe_mismatch(other, want[:3]))
+    monkeypatch.delenv("FIMEX_AMD_FWD_TILED_SLOTS")
+    for tw in ("8", "64", "4"):
+        monkeypatch.setenv("FIMEX_AMD_FWD_TILE_W", tw)
+        p2 = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+        assert p2.info()["tileW"] in (0, int(tw))  # 0: this shape cannot be staged with tiles of that width (lane kernels)
+        other = p2.apply_host(f)
+        assert cases.same(other, want), (tw, cases.describe_mismatch(other, want))
+    monkeypatch.setenv("FIMEX_AMD_FWD_TILED", "0")
+    p3 = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    assert p3.info()["stagedCells"] == 0
+    lanes = p3.apply_host(f)
+    assert cases.same(lanes, want), cases.describe_mismatch(lanes, want)
+
+
 @pytest.mark.parametrize("method", FORWARD)
 @pytest.mark.parametrize("shape,density", [((150, 120, 64, 50), 0.08), ((150, 120, 63, 51), 0.08), ((300, 200, 100, 80), 0.5), ((200, 150, 40, 36), 2.5)])
 def test_forward_sparse_mappings_and_short_median(fa, monkeypatch, method, shape, density, tuning_build):

@@ -333,7 +333,7 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
     const size_t nonEmpty = nOut - plan.info.undefinedCells;
     const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
     if (plan.aggregate == Aggregate::Median) return;  // the median ranks a bucket's values in registers (forward.hip)
-    if (meanBucket < (double)tuning("FWD_TILED_MIN", 16) || tuning("FWD_TILED", 1) == 0) return;
+    if (meanBucket < (double)tuning("FWD_TILED_MIN", 4) || tuning("FWD_TILED", 1) == 0) return;
     // Tile shape: 16 x 4 targets where that can be staged, else (a mapping that turns the grids against each other makes wide tiles
     // span many source rows) 8 x 8, 32 x 2, 4 x 16 -- of the shapes that can, the one that stages the fewest chunks.
     const int forced = tuning("FWD_TILE_W", 0);
@@ -410,7 +410,7 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
 bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
 {
     const ForwardTiles& ft = plan.fwdTiles;
-    if (!ft.valid || plan.aggregate == Aggregate::Median) return false;
+    if (!ft.valid || plan.aggregate == Aggregate::Median || tuning("FWD_TILED", 1) == 0) return false;
     FtArgs a{};
     a.in = d_in;
     a.out = d_out;

@@ -61,23 +61,27 @@ def main():
                  mapped_source_cells=info["mappedSourceCells"], source_granules_64B=granules, plan_bytes=info["planBytes"], cells=nz * fw.inX * fw.inY,
                  note="bytes_must_move = per slice the 64-byte pieces of the source that hold a mapped cell + the output, + the CSR plan once; "
                       "SURVEY 8d's formula charges the whole source slice although 4 % of it maps into the target")
-    elif a.case.startswith("forwarddense_"):
+    elif a.case.startswith("forwarddense"):
         # a dense forward mapping: the same 0.1-degree global source onto a 1-degree global lat/lon grid, 100 source cells per bucket
         # (the wave-per-bucket kernels: coalesced index loads, ballot, ordered lane fold)
+        # forwarddense_<aggregate>: onto 1 degree (100 cells per bucket); forwarddense<k>_<aggregate>: onto 1/k degree (k = 2: 25 cells, k = 4: 4-9 cells)
         fw = workloads.ForwardLambert()
-        tx = (np.arange(360) - 179.5); ty = (np.arange(180) - 89.5)
+        head, aggr = a.case.split("_")
+        k = int(head[len("forwarddense"):] or 1)
+        ox, oy = 360 * k, 180 * k
+        tx = (np.arange(ox) + 0.5) / k - 180.0; ty = (np.arange(oy) + 0.5) / k - 90.0
         lon, lat = np.meshgrid(fw.src_lon, fw.src_lat)
         px = workloads.axis_positions_numpy(lon.ravel(), tx); py = workloads.axis_positions_numpy(lat.ravel(), ty)
-        m = {"forwarddense_mean": fa.FORWARD_MEAN, "forwarddense_max": fa.FORWARD_MAX, "forwarddense_median": fa.FORWARD_MEDIAN}[a.case]
+        m = {"mean": fa.FORWARD_MEAN, "max": fa.FORWARD_MAX, "median": fa.FORWARD_MEDIAN, "sum": fa.FORWARD_SUM}[aggr]
         nz = 100
         d_in = bench.make_slices(torch, fw.base_field(), nz)
-        d_out = torch.empty((nz, 180, 360), dtype=torch.float32, device="cuda")
-        plan = fa.RegridPlan(m, px, py, fw.inX, fw.inY, 360, 180)
+        d_out = torch.empty((nz, oy, ox), dtype=torch.float32, device="cuda")
+        plan = fa.RegridPlan(m, px, py, fw.inX, fw.inY, ox, oy)
         info = plan.info()
         ts = timed(lambda: plan.apply_device(d_in.data_ptr(), nz, d_out.data_ptr(), st))
-        r.update(workload="0.1-degree global 3600x1800 -> 1-degree global 360x180, forward, %d slices, %d source cells per bucket at most" % (nz, info["maxBucket"]),
-                 kernel_pattern="forward_apply", bytes_survey_8d=nz * 4 * (fw.inX * fw.inY + 360 * 180) + info["planBytes"], cells=nz * fw.inX * fw.inY,
-                 mapped_source_cells=info["mappedSourceCells"], plan_bytes=info["planBytes"])
+        r.update(workload="0.1-degree global 3600x1800 -> 1/%d-degree global %dx%d, forward, %d slices, %d source cells per bucket at most" % (k, ox, oy, nz, info["maxBucket"]),
+                 kernel_pattern="forward_apply", bytes_survey_8d=nz * 4 * (fw.inX * fw.inY + ox * oy) + info["planBytes"], cells=nz * fw.inX * fw.inY,
+                 mapped_source_cells=info["mappedSourceCells"], plan_bytes=info["planBytes"], staged_cells_per_slice=info["stagedCells"], tile=[info["tileW"], info["tileH"]])
         r["bytes_must_move"] = r["bytes_survey_8d"]
     elif a.case in ("rotate_values", "rotate_direction"):
         wl = workloads.BilinearRotatedPole()

@@ -1081,6 +1081,9 @@ def test_forward_dense_mappings(fa, monkeypatch, method, shape, density, tuning_
     got = plan.apply_host(f)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
     assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(want[~np.isnan(want)]))
+    monkeypatch.setenv("FIMEX_AMD_FWD_TILED", "0")
+    lanes = plan.apply_host(f)   # sums and extrema: the lane kernels with look-ahead instead of the LDS-staged kernel
+    assert cases.same(lanes, want), cases.describe_mismatch(lanes, want)
     monkeypatch.setenv("FIMEX_AMD_FWD_MEDIAN_WAVE", "0")
     monkeypatch.setenv("FIMEX_AMD_FWD_WAVE", "1")
     other = plan.apply_host(f)   # the other kernels of the same method: rank counting per lane, wave per bucket

@@ -356,6 +356,93 @@ __global__ void __launch_bounds__(kBlock) forward_apply_median_wave(FwdArgs a)
     }
 }
 
+// The same median by SELECTION instead of ranking: the kept values of a bucket, as keys whose unsigned order is the floats' order,
+// sit in Q registers per lane; the key of rank size() / 2 is built bit by bit from the top -- "how many keys lie below the candidate?"
+// is one comparison per register, whose result IS the ballot, a population count and a scalar decision: 32 rounds of Q vector and a
+// handful of scalar instructions, whatever the bucket's length (ranking: one broadcast and 2 Q comparisons per VALUE; 100 cells per
+// bucket, 100 slices: 13.1 ms -> see DESIGN.md 6).  The value comes back out of the key.  Only +0.0 and -0.0 compare equal without
+// being the same bits: they share a key, and where the median is a zero, the order the reference's result follows ("less, or equal
+// and earlier", src/CachedForwardInterpolation.cc:49-53) picks among the bucket's zeros by position.
+template <bool UNDEF, int Q>
+__global__ void __launch_bounds__(kBlock) forward_apply_median_select(FwdArgs a)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= a.nOut) return;  // wave-uniform
+    const uint32_t z0 = blockIdx.y * a.zPerBlock;
+    const uint32_t z1 = min(a.nz, z0 + a.zPerBlock);
+    const uint32_t b = a.offsets[t], n0 = a.offsets[t + 1] - b;
+    if (n0 == 0) {
+        if (lane == 0)
+            for (uint32_t z = z0; z < z1; ++z) a.out[(size_t)z * a.nOut + t] = undefined_f();
+        return;
+    }
+    uint32_t idx[Q];
+    bool has[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const uint32_t p = (uint32_t)q * kWave + lane;
+        has[q] = p < n0;
+        idx[q] = has[q] ? a.src[b + p] : 0u;
+    }
+    constexpr uint32_t kZeroKey = 0x80000000u;
+    for (uint32_t z = z0; z < z1; ++z) {
+        const float* src = a.in + (size_t)z * a.inLayer;
+        float v[Q];
+        uint32_t key[Q];
+        bool nanHere = false;
+        uint32_t n = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            v[q] = has[q] ? src[idx[q]] : 0.f;
+            const bool kept = has[q] && keep<UNDEF>(v[q]);
+            nanHere = nanHere || (has[q] && isnan(v[q]));
+            n += (uint32_t)__popcll(__ballot(kept));
+            const uint32_t bits = __float_as_uint(v[q]);
+            const uint32_t ordered = bits ^ (((int32_t)bits < 0) ? 0xFFFFFFFFu : 0x80000000u);  // unsigned order = float order
+            key[q] = !kept ? 0xFFFFFFFFu : (v[q] == 0.f ? kZeroKey : ordered);                    // dropped: above every kept value
+        }
+        const bool anyNan = __ballot(nanHere) != 0;
+        float* o = a.out + (size_t)z * a.nOut + t;
+        // a NaN inside an "undef" bucket: the reference's nth_element result is implementation-defined; value + undef = undef is kept
+        if (n == 0 || (UNDEF && anyNan)) {
+            if (lane == 0) *o = undefined_f();
+            continue;
+        }
+        const uint32_t want = n / 2;
+        uint32_t K = 0;  // the largest candidate with at most `want` keys below it = the key of rank `want`
+#pragma unroll
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t T = K | (1u << bit);
+            uint32_t below = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) below += (uint32_t)__popcll(__ballot(key[q] < T));
+            K = (below <= want) ? T : K;
+        }
+        uint32_t bits = (K & 0x80000000u) ? (K ^ 0x80000000u) : ~K;
+        if (K == kZeroKey) {
+            // the median is a zero: the (want - #negative values)-th of the bucket's zeros in scan order supplies the sign
+            uint32_t k = want;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) k -= (uint32_t)__popcll(__ballot(key[q] < kZeroKey));
+            bool found = false;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                unsigned long long m = __ballot(key[q] == kZeroKey);
+                const uint32_t c = (uint32_t)__popcll(m);
+                if (!found && k < c) {
+                    for (uint32_t i = 0; i < k; ++i) m &= m - 1;
+                    bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v[q]), __ffsll((long long)m) - 1);
+                    found = true;
+                } else if (!found) {
+                    k -= c;
+                }
+            }
+        }
+        if (lane == 0) *o = __uint_as_float(bits);
+    }
+}
+
 template <int KIND, bool UNDEF>
 void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, bool longBuckets, hipStream_t stream)
 {
@@ -499,14 +586,22 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
             // no bucket holds more than one cell (a source grid coarser than the target, configs[3]): the median of one value is
             // the value, which is what the max kernel returns for it bit for bit -- without the median's per-slice state
             u ? launch_kind<3, true>(a, gridLane, false, false, stream) : launch_kind<3, false>(a, gridLane, false, false, stream);
-        } else if (a.rankAll == 0 && plan.info.maxBucket > 2 && plan.info.maxBucket <= 256 && meanBucket >= 4.0 && tuning("FWD_MEDIAN_WAVE", 1) != 0) {
-            // medium buckets throughout (a source finer than the target): one wave per target, ranks by broadcast
+        } else if (a.rankAll == 0 && plan.info.maxBucket > 2 && plan.info.maxBucket <= 256 && meanBucket >= (double)tuning("FWD_MEDIAN_WAVE_MIN", 12) && tuning("FWD_MEDIAN_WAVE", 1) != 0) {
+            // medium buckets throughout (a source finer than the target): one wave per target, the median by selection on keys.  Its
+            // cost does not depend on the bucket's length (25 ms per 100 slices of a million targets), the lane kernel's rank counting
+            // grows with its square (6.3 ms at 4-9 cells, about 32 at 25): a wave per target from a mean length of twelve
             const dim3 g((uint32_t)ceil_div(a.nOut, kBlock / kWave), gridLane.y, 1);
-            if (plan.info.maxBucket <= 128) {
-                if (u) forward_apply_median_wave<true, 2><<<g, kBlock, 0, stream>>>(a);
+            const bool select = tuning("FWD_MEDIAN_SELECT", 1) != 0;  // 0: ranks by broadcast (the form before it)
+            if (plan.info.maxBucket <= 64 && select) {
+                if (u) forward_apply_median_select<true, 1><<<g, kBlock, 0, stream>>>(a);
+                else forward_apply_median_select<false, 1><<<g, kBlock, 0, stream>>>(a);
+            } else if (plan.info.maxBucket <= 128) {
+                if (select) { if (u) forward_apply_median_select<true, 2><<<g, kBlock, 0, stream>>>(a); else forward_apply_median_select<false, 2><<<g, kBlock, 0, stream>>>(a); }
+                else if (u) forward_apply_median_wave<true, 2><<<g, kBlock, 0, stream>>>(a);
                 else forward_apply_median_wave<false, 2><<<g, kBlock, 0, stream>>>(a);
             } else {
-                if (u) forward_apply_median_wave<true, 4><<<g, kBlock, 0, stream>>>(a);
+                if (select) { if (u) forward_apply_median_select<true, 4><<<g, kBlock, 0, stream>>>(a); else forward_apply_median_select<false, 4><<<g, kBlock, 0, stream>>>(a); }
+                else if (u) forward_apply_median_wave<true, 4><<<g, kBlock, 0, stream>>>(a);
                 else forward_apply_median_wave<false, 4><<<g, kBlock, 0, stream>>>(a);
             }
         } else if (plan.info.maxBucket > 2 || a.rankAll != 0) {

@@ -1064,8 +1064,9 @@ def test_release_caches_between_host_calls(fa):
 @pytest.mark.parametrize("shape,density", [((240, 200, 40, 30), 1.2), ((240, 200, 40, 30), 7.0), ((300, 256, 64, 48), 3.0)])
 def test_forward_dense_mappings(fa, monkeypatch, method, shape, density, tuning_build):
     """A source finer than the target (what forward interpolation is for): tens to a couple of hundred source cells per bucket.  The
-    median goes through the wave kernel (ranks by broadcast, two or four registers of bucket values per lane), sums and extrema through
-    the lane kernels with eight cells of look-ahead; NaNs, signed zeros and many equal values in the data.  Same bits as the oracle,
+    median goes through the wave kernels (selection on keys, one to four registers of bucket values per lane -- zeros of either sign
+    as the median included; before it: ranks by broadcast), sums and extrema through the LDS-staged kernel or the lane kernels with
+    eight cells of look-ahead; NaNs, signed zeros and many equal values in the data.  Same bits as the oracle from every one of them,
     and as the rank-counting median of the lane kernel."""
     inX, inY, outX, outY = shape
     nz = 5
@@ -1084,6 +1085,14 @@ def test_forward_dense_mappings(fa, monkeypatch, method, shape, density, tuning_
     monkeypatch.setenv("FIMEX_AMD_FWD_TILED", "0")
     lanes = plan.apply_host(f)   # sums and extrema: the lane kernels with look-ahead instead of the LDS-staged kernel
     assert cases.same(lanes, want), cases.describe_mismatch(lanes, want)
+    monkeypatch.setenv("FIMEX_AMD_FWD_MEDIAN_WAVE_MIN", "1")
+    selected = plan.apply_host(f)  # the median by selection on keys also where the plan's buckets are short on average
+    assert cases.same(selected, want), cases.describe_mismatch(selected, want)
+    assert np.array_equal(np.signbit(selected[~np.isnan(selected)]), np.signbit(want[~np.isnan(want)]))
+    monkeypatch.setenv("FIMEX_AMD_FWD_MEDIAN_SELECT", "0")
+    ranked = plan.apply_host(f)  # the median by ranks (broadcasts) instead of by selection on keys
+    assert cases.same(ranked, want), cases.describe_mismatch(ranked, want)
+    assert np.array_equal(np.signbit(ranked[~np.isnan(ranked)]), np.signbit(want[~np.isnan(want)]))
     monkeypatch.setenv("FIMEX_AMD_FWD_MEDIAN_WAVE", "0")
     monkeypatch.setenv("FIMEX_AMD_FWD_WAVE", "1")
     other = plan.apply_host(f)   # the other kernels of the same method: rank counting per lane, wave per bucket

@@ -190,7 +190,7 @@ __device__ __forceinline__ void take_plain(float v, float& acc, uint32_t& cnt)
 }
 
 // Slices z0 .. z1 of one tile, by one wave.
-template <int KIND, bool UNDEF, int G>
+template <int KIND, bool UNDEF, int G, int KMAX>
 __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint32_t z0, uint32_t z1)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // the workgroup's dynamic LDS
@@ -236,9 +236,9 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
     // staging list: chunk c = lane + 64 * j of the tile (byte offset of its 16 bytes inside a source slice); lanes beyond the list
     // repeat its last chunk into the unused tail of the slot (no selection here: the compiler turns one into a branch and a
     // wait around every one of these loads)
-    uint32_t gOff[kFtKmax];
+    uint32_t gOff[KMAX];
 #pragma unroll
-    for (uint32_t j = 0; j < kFtKmax; ++j) {
+    for (uint32_t j = 0; j < (uint32_t)KMAX; ++j) {
         const uint32_t c = lane + j * kWave;
         gOff[j] = a.chunkOff[T.chunkBase + min(c, T.nChunks - 1)] * 4u;
     }
@@ -249,7 +249,7 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
         uint32_t n = (kTuningBuild && (a.ablate & 1)) ? 0u : un;
         asm volatile("" : "+s"(n));  // compared afresh: hoisted out of the slice loop the 32 conditions cost 64 scalar registers
 #pragma unroll
-        for (uint32_t j = 0; j < kFtKmax; ++j)
+        for (uint32_t j = 0; j < (uint32_t)KMAX; ++j)
             if (j < n) dma16(rs, dst + j * kWave * 4u, gOff[j], kTuningBuild ? a.loadAux : 0u);
     };
     const bool two = a.slots == 2;
@@ -305,21 +305,26 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
 // (Measured against it: as many waves as the chip holds, each with an equal run of (tile, slice) pairs -- no last round for a few
 // tiles, but all waves of a CU then stage and walk in step, 0.66 ms against 0.57 for the dense case of DESIGN.md 6; workgroups that
 // start whenever one ends keep the phases apart.)
-template <int KIND, bool UNDEF, int G>
+template <int KIND, bool UNDEF, int G, int KMAX>
 __global__ void __launch_bounds__(kWave) forward_apply_tiled(FtArgs a)
 {
     const uint32_t perXcd = gridDim.x / kXcds;
     const uint32_t tile = (blockIdx.x % kXcds) * perXcd + blockIdx.x / kXcds;
     if (tile >= a.g.nTiles) return;
-    tile_slices<KIND, UNDEF, G>(a, tile, a.zStart[blockIdx.y], a.zStart[blockIdx.y + 1]);
+    tile_slices<KIND, UNDEF, G, KMAX>(a, tile, a.zStart[blockIdx.y], a.zStart[blockIdx.y + 1]);
 }
 
+// G groups of eight steps in registers, KMAX chunks per lane and slice: the smallest form that holds the plan's longest bucket and
+// largest tile -- short buckets take few registers and many waves per SIMD, which is what hides the wait for a slice there
 template <int KIND, bool UNDEF>
 void launch_tiled(const FtArgs& a, uint32_t groups, dim3 grid, size_t lds, hipStream_t stream)
 {
-    if (groups <= 8) forward_apply_tiled<KIND, UNDEF, 8><<<grid, kWave, lds, stream>>>(a);
-    else if (groups <= 16) forward_apply_tiled<KIND, UNDEF, 16><<<grid, kWave, lds, stream>>>(a);
-    else forward_apply_tiled<KIND, UNDEF, 32><<<grid, kWave, lds, stream>>>(a);
+    const uint32_t kmax = a.slotChunks / kWave;
+    if (groups <= 2 && kmax <= 4) forward_apply_tiled<KIND, UNDEF, 2, 4><<<grid, kWave, lds, stream>>>(a);
+    else if (groups <= 4 && kmax <= 8) forward_apply_tiled<KIND, UNDEF, 4, 8><<<grid, kWave, lds, stream>>>(a);
+    else if (groups <= 8 && kmax <= 16) forward_apply_tiled<KIND, UNDEF, 8, 16><<<grid, kWave, lds, stream>>>(a);
+    else if (groups <= 16) forward_apply_tiled<KIND, UNDEF, 16, 32><<<grid, kWave, lds, stream>>>(a);
+    else forward_apply_tiled<KIND, UNDEF, 32, 32><<<grid, kWave, lds, stream>>>(a);
 }
 
 }  // namespace

@@ -252,50 +252,50 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
         for (uint32_t j = 0; j < (uint32_t)KMAX; ++j)
             if (j < n) dma16(rs, dst + j * kWave * 4u, gOff[j], kTuningBuild ? a.loadAux : 0u);
     };
-    const bool two = a.slots == 2;
+    // a.slots slices per pass: all of them are asked for, then waited for, then reduced one after the other.  One by default: with
+    // long buckets LDS bounds the waves of a CU (a second slot for a prefetch halved them and lost), with short ones
+    // several slices per wave in flight gained nothing
     if (lane < a.slots) smem[lane * slotFloats + a.slotChunks * 4u] = padding_value<KIND, UNDEF>();
-    __builtin_amdgcn_s_waitcnt(0x0070);  // every load so far has returned: nothing in the loop waits behind a DMA for one of them
+    // every load so far has returned (the builtin, not inline assembly: the compiler's own counter tracking must see these waits, or
+    // it waits for the loads of before the loop, behind the DMAs, inside the walk)
+    __builtin_amdgcn_s_waitcnt(0x0070);
     asm volatile("" ::: "memory");
-    dma(0, z0);
-    uint32_t slot = 0;
-    for (uint32_t z = z0; z < z1; ++z) {
-        // slice z has landed (and the step table, first time round).  The builtin, not inline assembly: the compiler's own counter
-        // tracking must see this wait, or it waits for the loads of before the loop -- behind the prefetch just issued -- inside the walk
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    for (uint32_t zp = z0; zp < z1; zp += a.slots) {
+        const uint32_t here = min(a.slots, z1 - zp);
+        for (uint32_t sl = 0; sl < here; ++sl) dma(sl, zp + sl);
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the slices of this pass have landed
         asm volatile("" ::: "memory");
-        if (two && z + 1 < z1) dma(slot ^ 1u, z + 1);
-        const char* cur = reinterpret_cast<const char*>(&smem[slot * slotFloats]);
-        float acc = start_value<KIND, UNDEF>();
-        uint32_t cnt = 0;
-        // the walk, eight steps at a time: the values of group k + 1 are on their way while group k is reduced
-        auto values = [&](int k, float (&v)[kFtGroup]) __attribute__((always_inline)) {
+        for (uint32_t sl = 0; sl < here; ++sl) {
+            const uint32_t z = zp + sl;
+            const char* cur = reinterpret_cast<const char*>(&smem[sl * slotFloats]);
+            float acc = start_value<KIND, UNDEF>();
+            uint32_t cnt = 0;
+            // the walk, eight steps at a time: the values of group k + 1 are on their way while group k is reduced
+            auto values = [&](int k, float (&v)[kFtGroup]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[2 * i] = *reinterpret_cast<const float*>(cur + (tr[4 * k + i] & 0xFFFFu));
-                v[2 * i + 1] = *reinterpret_cast<const float*>(cur + (tr[4 * k + i] >> 16));
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = *reinterpret_cast<const float*>(cur + (tr[4 * k + i] & 0xFFFFu));
+                    v[2 * i + 1] = *reinterpret_cast<const float*>(cur + (tr[4 * k + i] >> 16));
+                }
+            };
+            float v[kFtGroup], vn[kFtGroup];
+            values(0, v);
+            const bool firstNan = v[0] != v[0];
+            const uint32_t walk = (kTuningBuild && (a.ablate & 2)) ? 0u : groups;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if ((uint32_t)k < walk) {  // wave-uniform
+                    if (k + 1 < G) values(k + 1, vn);
+#pragma unroll
+                    for (uint32_t i = 0; i < kFtGroup; ++i) take<KIND, UNDEF>(v[i], acc, cnt);
+#pragma unroll
+                    for (uint32_t i = 0; i < kFtGroup; ++i) v[i] = vn[i];
+                }
             }
-        };
-        float v[kFtGroup], vn[kFtGroup];
-        values(0, v);
-        const bool firstNan = v[0] != v[0];
-        const uint32_t walk = (kTuningBuild && (a.ablate & 2)) ? 0u : groups;
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            if ((uint32_t)k < walk) {  // wave-uniform
-                if (k + 1 < G) values(k + 1, vn);
-#pragma unroll
-                for (uint32_t i = 0; i < kFtGroup; ++i) take<KIND, UNDEF>(v[i], acc, cnt);
-#pragma unroll
-                for (uint32_t i = 0; i < kFtGroup; ++i) v[i] = vn[i];
-            }
+            if (mine) __builtin_nontemporal_store(finish<KIND, UNDEF>(acc, cnt, len, firstNan), a.out + (size_t)z * a.nOut + t);
         }
-        if (mine) __builtin_nontemporal_store(finish<KIND, UNDEF>(acc, cnt, len, firstNan), a.out + (size_t)z * a.nOut + t);
-        if (two) slot ^= 1u;
-        else if (z + 1 < z1) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the reads of this slice are done before the next one overwrites it
-            asm volatile("" ::: "memory");
-            dma(0, z + 1);
-        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the reads of this pass are done before the next one overwrites the slots
+        asm volatile("" ::: "memory");
     }
     wait_vmcnt<0>();
 }
@@ -339,10 +339,14 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
     const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
     if (plan.aggregate == Aggregate::Median) return;  // the median ranks a bucket's values in registers (forward.hip)
     if (meanBucket < (double)tuning("FWD_TILED_MIN", 4) || tuning("FWD_TILED", 1) == 0) return;
-    // Tile shape: 16 x 4 targets where that can be staged, else (a mapping that turns the grids against each other makes wide tiles
-    // span many source rows) 8 x 8, 32 x 2, 4 x 16 -- of the shapes that can, the one that stages the fewest chunks.
+    // Tile shape: the wider the tile, the longer the runs of a source row it stages (what the staging loads like: 1/4-degree targets
+    // from 0.1 degree, 4-9 cells per bucket, 100 slices: 0.66 ms with 16 x 4 tiles, 0.58 with 32 x 2, 0.63 with 64 x 1, 0.97 with
+    // 8 x 8; 100 cells per bucket: no difference between 16, 32 and 64) -- 32 x 2 for short buckets, 16 x 4 for long ones, whose
+    // tiles fill a slot sooner; where that shape cannot be staged (a mapping that turns the grids against each other makes wide tiles
+    // span many source rows) the other shapes are tried and the one that stages the fewest chunks is kept.
     const int forced = tuning("FWD_TILE_W", 0);
-    std::vector<uint32_t> widths = {16, 8, 32, 4};
+    const uint32_t first = meanBucket >= 50.0 ? 16u : 32u;
+    std::vector<uint32_t> widths = {first, first == 16u ? 32u : 16u, 8, 4};
     if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) widths = {(uint32_t)forced};
     FtGeom g{};
     std::vector<FtTile> h;
@@ -385,7 +389,7 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
         found = true;
         g = c; h.swap(hc); nTiles = n;
         chunks = cChunks; stepEntries = cSteps; direct = cDirect; staged = cStaged; maxChunks = cMaxChunks; maxLen = cMaxLen;
-        if (tw == 16) break;  // the default shape where it works
+        if (tw == first) break;  // the preferred shape where it works
     }
     if (!found) return;
     ft.tiles.allocate(nTiles);
@@ -431,11 +435,13 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.nz = (uint32_t)nz;
     a.slotChunks = ft.slotChunks;
     a.tableBytes = ft.tableBytes;
-    // one slice of the tile in LDS per wave: two (the next one streaming in while this one is reduced) halve the waves a CU holds;
-    // two only where six waves per CU fit all the same
+    // slices per pass (see tile_slices): one.  Several (tuning build) were no faster where a slice of a tile is small (1/4-degree
+    // targets, 2 KB per slice: 0.69 ms with one or two, 0.71 with four, 0.73 with eight): the staging loads' run length is what
+    // bounds those launches, not a wave's wait
     const size_t slotBytes = ((size_t)ft.slotChunks + 1) * 16;  // + the padding cell's chunk
     int slots = tuning("FWD_TILED_SLOTS", 0);
-    if (slots != 1 && slots != 2) slots = (2 * slotBytes <= 26 * 1024) ? 2 : 1;
+    if (slots < 1 || slots > 8) slots = 1;
+    slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(nz, 1));
     a.slots = (uint32_t)slots;
     a.ablate = (uint32_t)tuning("FWD_TILED_ABLATE", 0);
     a.loadAux = (uint32_t)tuning("FWD_TILED_AUX", 0);

@@ -1108,7 +1108,7 @@ def test_forward_tiled_mappings(fa, monkeypatch, method, shape, density, special
     Rotated, wavy mappings, target grids that are no multiple of the tile, source rows of odd length (chunks are cut on multiples
     of four cells of the slice, not of the row), NaNs / signed zeros / equal values, `special`: source cells thrown to the corners
     and edges of the target (buckets whose cells lie far apart: tiles that cannot be staged read from memory).  Same bits as the
-    oracle with either tile shape, one or two slices in LDS, and as the lane kernels."""
+    oracle with every tile shape, one to eight slices of a tile in LDS per pass, and as the lane kernels."""
     inX, inY, outX, outY = shape
     nz = 7
     px, py = cases.forward_positions(inX, inY, outX, outY, seed=31, density=density, special=special)
@@ -1125,7 +1125,7 @@ def test_forward_tiled_mappings(fa, monkeypatch, method, shape, density, special
     got = plan.apply_host(f)
     assert cases.same(got, want), cases.describe_mismatch(got, want)
     assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(want[~np.isnan(want)]))
-    for slots in ("1", "2"):
+    for slots in ("1", "3", "8"):
         monkeypatch.setenv("FIMEX_AMD_FWD_TILED_SLOTS", slots)
         other = plan.apply_host(f[:3])
         assert cases.same(other, want[:3]), (slots, cases.describe_mismatch(other, want[:3]))

@@ -338,7 +338,9 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
     const size_t nonEmpty = nOut - plan.info.undefinedCells;
     const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
     if (plan.aggregate == Aggregate::Median) return;  // the median ranks a bucket's values in registers (forward.hip)
-    if (meanBucket < (double)tuning("FWD_TILED_MIN", 4) || tuning("FWD_TILED", 1) == 0) return;
+    // from 2.5 cells per bucket on average: 0.1-degree source onto 1/6 degree (2.8 cells) 0.83 ms staged against 0.94 through the lane
+    // kernels, onto 1/8 degree (1.6 cells) 1.20 against 0.99, configs[3] (sparse) 0.66 against 0.22
+    if (meanBucket * 10.0 < (double)tuning("FWD_TILED_MIN_TENTHS", 25) || tuning("FWD_TILED", 1) == 0) return;
     // Tile shape: the wider the tile, the longer the runs of a source row it stages (what the staging loads like: 1/4-degree targets
     // from 0.1 degree, 4-9 cells per bucket, 100 slices: 0.66 ms with 16 x 4 tiles, 0.58 with 32 x 2, 0.63 with 64 x 1, 0.97 with
     // 8 x 8; 100 cells per bucket: no difference between 16, 32 and 64) -- 32 x 2 for short buckets, 16 x 4 for long ones, whose

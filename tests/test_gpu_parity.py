@@ -1143,6 +1143,34 @@ def test_forward_tiled_mappings(fa, monkeypatch, method, shape, density, special
     assert cases.same(lanes, want), cases.describe_mismatch(lanes, want)
 
 
+@pytest.mark.parametrize("method", [oracle.FWD_MEAN, oracle.FWD_UNDEF_SUM, oracle.FWD_UNDEF_MIN, oracle.FWD_MAX, oracle.FWD_MEDIAN, oracle.FWD_UNDEF_MEDIAN])
+@pytest.mark.parametrize("shape,nz", [((40, 28, 3, 2), 1), ((40, 28, 3, 2), 2), ((64, 48, 5, 70), 3), ((40, 30, 4, 3), 1300), ((257, 129, 33, 17), 37)])
+def test_forward_tiled_edges(fa, method, shape, nz):
+    """The LDS-staged forward kernel and the selection median at the edges of their launch geometry: target grids smaller than one
+    tile, one and two slices (a single z chunk), more slices than the z chunks of one launch hold at four each (the chunk length
+    grows), a slice count that leaves a short last chunk; whole slices of NaN, of +0.0, of -0.0 and of +-inf among them."""
+    inX, inY, outX, outY = shape
+    j, i = np.meshgrid(np.arange(inY, dtype=np.float64), np.arange(inX, dtype=np.float64), indexing="ij")
+    px = ((i + 0.5) * outX / inX - 0.5 + 0.2 * np.sin(j / 7.0)).ravel()   # every source cell maps: buckets of inX * inY / (outX * outY) cells
+    py = ((j + 0.5) * outY / inY - 0.5 + 0.2 * np.cos(i / 5.0)).ravel()
+    f = cases.field(nz, inY, inX, seed=90 + method, nan_frac=0.04)
+    for k, v in enumerate((np.nan, 0.0, -0.0, np.inf, -np.inf)):
+        if k < nz:
+            f[(k * 7) % nz] = np.float32(v)
+    if nz > 6:
+        f[5, ::2, :] = np.float32(-0.0)   # zeros of both signs inside every bucket: the median's tie-break, the sums' sign
+        f[5, 1::2, :] = np.float32(0.0)
+    want = oracle.forward_interpolate_values(method, px, py, f, inX, inY, outX, outY)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    info = plan.info()
+    assert 8 <= info["maxBucket"] <= 256, info
+    if method not in (oracle.FWD_MEDIAN, oracle.FWD_UNDEF_MEDIAN):
+        assert info["stagedCells"] > 0, info
+    got = plan.apply_host(f)
+    assert cases.same(got, want), cases.describe_mismatch(got, want)
+    assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(want[~np.isnan(want)]))
+
+
 @pytest.mark.parametrize("method", FORWARD)
 @pytest.mark.parametrize("shape,density", [((150, 120, 64, 50), 0.08), ((150, 120, 63, 51), 0.08), ((300, 200, 100, 80), 0.5), ((200, 150, 40, 36), 2.5)])
 def test_forward_sparse_mappings_and_short_median(fa, monkeypatch, method, shape, density, tuning_build):

@@ -451,6 +451,14 @@ void launch_kind(const FwdArgs& a, dim3 grid, bool wavePath, bool longBuckets, h
         forward_apply_wave<KIND, UNDEF><<<g, kBlock, 0, stream>>>(a);
     } else if (longBuckets) {
         forward_apply_lane<KIND, UNDEF, kLaneZc, false, 8><<<grid, kBlock, 0, stream>>>(a);
+    } else if (a.nz == 1) {
+        // one slice per call is the reference's own call pattern (src/CDMInterpolator.cc:251-259): no eight-slice passes that read
+        // the one slice eight times (configs[3], one slice: see DESIGN.md 6)
+        forward_apply_lane<KIND, UNDEF, 1><<<grid, kBlock, 0, stream>>>(a);
+    } else if (a.nz <= 2) {
+        forward_apply_lane<KIND, UNDEF, 2><<<grid, kBlock, 0, stream>>>(a);
+    } else if (a.nz <= 4) {
+        forward_apply_lane<KIND, UNDEF, 4><<<grid, kBlock, 0, stream>>>(a);
     } else {
         forward_apply_lane<KIND, UNDEF, kLaneZc><<<grid, kBlock, 0, stream>>>(a);
     }

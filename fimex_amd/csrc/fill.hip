@@ -14,6 +14,8 @@
 // the first guess is bit-identical too.
 #include "plan.hpp"
 
+#include <cstdio>
+
 #include <vector>
 
 namespace fimex_amd {
@@ -28,6 +30,8 @@ struct SliceStats {
     double meanAbsDev;  // fill2d: relaxCrit * mean absolute deviation = the convergence criterion
     int status;         // 1 ok, -1 error
     int skip;           // nothing to fill or nothing defined: the slice is left alone
+    unsigned long long sweepBound;  // creep fills: the loop ends after this many sweeps at the latest (:1430: the number of defined cells;
+                                    // for a rectangle of a decomposed fill: of the whole slice)
 };
 
 // sum of the defined values in scan order, double accumulator (interpolation.c:1256-1264, 1502-1513);
@@ -499,6 +503,7 @@ __global__ void __launch_bounds__(kWave) sum_stitch_kernel(SumJob j, SumWork w, 
         st->average = o.useDefault ? (double)o.defaultVal : ((nDef != 0) ? S / (double)nDef : 0.);
         st->status = 1;
         st->skip = (nDef == 0 || nUndef == 0);
+        st->sweepBound = nDef;
     } else {            // second pass: the convergence criterion (:1302)
         const unsigned long long nDef = o.total - st->nUndef;
         st->meanAbsDev = (double)o.relaxCrit * (S / (double)nDef);
@@ -689,6 +694,8 @@ struct FillStatsArgs {
     float defaultVal;
     float relaxCrit;
     int sumAlgo;
+    const double* defaults;  // per slice, instead of defaultVal (the rectangles of a decomposed creep fill: the whole slice's average)
+    const unsigned long long* bounds;  // per slice, with defaults: SliceStats::sweepBound
 };
 
 __global__ void __launch_bounds__(kFillBlock) fill_stats_kernel(FillStatsArgs a)
@@ -703,11 +710,12 @@ __global__ void __launch_bounds__(kFillBlock) fill_stats_kernel(FillStatsArgs a)
     if (threadIdx.x == 0) {
         const unsigned long long nDef = a.total - nUndef;
         shUndef = nUndef;
-        shAverage = a.useDefault ? (double)a.defaultVal : ((nDef != 0) ? sum / (double)nDef : 0.);  // :1281, :1516
+        shAverage = a.defaults ? a.defaults[blockIdx.x] : (a.useDefault ? (double)a.defaultVal : ((nDef != 0) ? sum / (double)nDef : 0.));  // :1281, :1516
         st->nUndef = nUndef;
         st->average = shAverage;
         st->status = 1;
         st->skip = (nDef == 0 || nUndef == 0);  // :1266-1269, :1384-1386
+        st->sweepBound = a.bounds ? a.bounds[blockIdx.x] : nDef;
     }
     __syncthreads();
     nUndef = shUndef;
@@ -785,9 +793,11 @@ __global__ void __launch_bounds__(kBlock) first_guess_kernel(FirstGuessArgs a)
 
 void launch_fill_prologue(bool creep, float* d_field, SliceStats* d_stats, size_t nx, size_t ny, size_t nz, uint32_t* mask, uint32_t mws,
                           unsigned char* mbRows, unsigned char* mbCols, bool wantDeviation, bool useDefault, float defaultVal, float relaxCrit,
-                          hipStream_t stream)
+                          hipStream_t stream, const double* d_defaults = nullptr, const unsigned long long* d_bounds = nullptr)
 {
     FillStatsArgs s{};
+    s.defaults = d_defaults;
+    s.bounds = d_bounds;
     s.field = d_field;
     s.stats = d_stats;
     s.total = nx * ny;
@@ -799,6 +809,7 @@ void launch_fill_prologue(bool creep, float* d_field, SliceStats* d_stats, size_
     // pass); many slices: one workgroup per slice fills the chip already and reads the data once
     s.sumAlgo = tuning("SUM_ALGO", 3);
     if (s.sumAlgo == 3) s.sumAlgo = nz < (size_t)tuning("SUM_CHIP_NZ", 100) ? 2 : 1;
+    if (d_defaults) s.sumAlgo = 1;  // only the undefined cells are counted
     if (s.sumAlgo >= 2) {
         const SumBuffers buffers(nx * ny, nz);
         StitchOut o{};
@@ -1531,6 +1542,8 @@ struct CreepArgs {
     unsigned short repeat;
     signed char setWeight;
     int sumAlgo;
+    const double* defaults;  // per slice, see FillStatsArgs
+    const unsigned long long* bounds;
 };
 
 __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
@@ -1551,7 +1564,7 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
     if (threadIdx.x == 0) {
         shUndef = nUndef;
         const unsigned long long nDef = total - nUndef;
-        shDefault = a.useDefault ? a.defaultVal : ((nDef != 0) ? (float)(sum / (double)nDef) : 0.f);  // :1516
+        shDefault = a.defaults ? (float)a.defaults[blockIdx.x] : (a.useDefault ? a.defaultVal : ((nDef != 0) ? (float)(sum / (double)nDef) : 0.f));  // :1516
         st->nUndef = nUndef;
         st->status = 1;
     }
@@ -1573,7 +1586,8 @@ __global__ void __launch_bounds__(kFillBlock) creepfill_kernel(CreepArgs a)
     const bool hasInterior = nx > 2 && ny > 2;
     unsigned long long l = 0;
     unsigned int changedInLoop = 1;
-    while (changedInLoop > 0 && l < nDef) {  // :1430
+    const unsigned long long bound = a.bounds ? a.bounds[blockIdx.x] : nDef;
+    while (changedInLoop > 0 && l < bound) {  // :1430
         l++;
         if (threadIdx.x == 0) shChanged = 0;
         __syncthreads();
@@ -2069,7 +2083,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v2(CreepV2Args
 
     // sum, first guess and the D mask were made by fill_stats_kernel / first_guess_kernel
     if (st->skip) return;  // :1384-1386, :1515
-    const unsigned long long nDef = total - st->nUndef;
+    const unsigned long long nDef = st->sweepBound;  // the loop's bound (:1430)
     const uint32_t repeat = a.repeat;
     const float swf = (float)a.setWeight;
 
@@ -2160,7 +2174,7 @@ __global__ void __launch_bounds__(kCreepThreads) creepfill_kernel_v3(CreepV2Args
     const MultiWg mg{g, G, 0u, sync + 4, a.error};
     const uint32_t wave = threadIdx.x / kWave;
     if (st->skip) return;  // :1384-1386, :1515
-    const unsigned long long nDef = total - st->nUndef;
+    const unsigned long long nDef = st->sweepBound;  // the loop's bound (:1430)
     const uint32_t repeat = a.repeat;
     const float swf = (float)a.setWeight;
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
@@ -2399,8 +2413,12 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
     collect_stats(stats, nz, h_nChanged, stream, "fill2d");
 }
 
-void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefault, float defaultVal,
-                   unsigned short repeat, char setWeight, size_t* h_nChanged, hipStream_t stream)
+namespace {
+
+// one run of the sweeps over whole slices [nz][ny][nx]; d_defaults (device, per slice) replaces the first guess
+void run_creepfill_whole(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefault, float defaultVal,
+                         unsigned short repeat, char setWeight, size_t* h_nChanged, hipStream_t stream, const double* d_defaults,
+                         const unsigned long long* d_bounds = nullptr)
 {
     if (nx * ny == 0 || nz == 0) return;  // :1380
     FA_REQUIRE(nx <= 0x7FFFFFFFu && ny <= 0x7FFFFFFFu && nz <= 0x7FFFFFFFu, "creepfill: slice too large");
@@ -2433,7 +2451,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
         a.skipIdle = tuning("CREEP_SKIP", 1);
         constexpr size_t ldsBytes = (size_t)kCreepWaves * kWave * kCreepPitch * sizeof(float) + (size_t)kCreepWaves * 2 * kHandWC * (sizeof(float) + 1) +
                                     (size_t)kCreepWaves * 4 * sizeof(unsigned int);
-        launch_fill_prologue(true, d_field, stats.get(), nx, ny, nz, maskD.get(), mws, nullptr, nullptr, false, useDefault, defaultVal, 0.f, stream);
+        launch_fill_prologue(true, d_field, stats.get(), nx, ny, nz, maskD.get(), mws, nullptr, nullptr, false, useDefault, defaultVal, 0.f, stream, d_defaults, d_bounds);
         DeviceArray<unsigned int> error(1);
         FA_HIP(hipMemsetAsync(error.get(), 0, sizeof(unsigned int), stream));
         a.error = error.get();
@@ -2485,9 +2503,267 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
     a.repeat = repeat;
     a.setWeight = (signed char)setWeight;
     a.sumAlgo = tuning("SUM_ALGO", 1);
+    a.defaults = d_defaults;
+    a.bounds = d_bounds;
     creepfill_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(a);
     FA_HIP(hipGetLastError());
     collect_stats(stats, nz, h_nChanged, stream, what);
+}
+
+// ---- creep fill by rectangles -----------------------------------------------------------------------------------------------
+// A cell that is defined on entry never changes and is read with the same weight (setWeight) whether it lies on a border or
+// inside (src/interpolation.c:1408-1461).  Rows and columns that are defined throughout therefore cut the field into rectangles
+// whose sweeps do not see each other, and a sweep that changes nothing ends a rectangle's loop without touching the others'
+// results (further sweeps over a finished region are no-ops).  The reference sweeps the whole field until nothing changes
+// anywhere: a region outside the source domain that lies ABOVE defined cells is filled one row per sweep (in-place, row-major:
+// values travel down and right within a sweep, up and left one cell per sweep) -- 185 sweeps over 3000 x 3000 cells for the
+// configs[4] field, of which a tenth of the field needs more than 22.  Here every rectangle (bounding box of a run of rows
+// with undefined cells x a run of columns with undefined cells inside those rows, plus the defined ring around it, or the
+// field's own border) is copied out, filled with the whole slice's first guess as a field of its own, and copied back.
+struct Rect {
+    uint32_t xa, xb, ya, yb;  // inclusive, ring included
+    bool operator==(const Rect& o) const { return xa == o.xa && xb == o.xb && ya == o.ya && yb == o.yb; }
+};
+
+// one wave per row: bit x of the row's words = cell x is undefined
+// rowCount[row] = undefined cells of the row
+__global__ void __launch_bounds__(kBlock) nan_bitmap_kernel(const float* __restrict__ field, uint32_t nx, size_t rows, uint32_t words,
+                                                            uint32_t* __restrict__ bits, uint32_t* __restrict__ rowCount)
+{
+    const size_t row = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (row >= rows) return;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const float* f = field + row * nx;
+    uint32_t* out = bits + row * words;
+    uint32_t count = 0;
+    for (uint32_t base = 0; base < words * 32; base += kWave) {
+        const uint32_t x = base + lane;
+        const unsigned long long m = __ballot(x < nx && isnan(f[x]));
+        count += (uint32_t)__popcll(m);
+        if (lane == 0) {
+            out[base / 32] = (uint32_t)m;
+            if (base / 32 + 1 < words) out[base / 32 + 1] = (uint32_t)(m >> 32);
+        }
+    }
+    if (lane == 0) rowCount[row] = count;
+}
+
+struct RectCopyArgs {
+    float* field;      // [nz][ny][nx], first slice of the group
+    float* box;        // [count][h][w]
+    size_t total;      // nx * ny
+    uint32_t nx, w, h, xa, ya;
+    int back;
+};
+__global__ void __launch_bounds__(kBlock) rect_copy_kernel(RectCopyArgs a)
+{
+    const uint32_t y = blockIdx.x % a.h, s = blockIdx.x / a.h;
+    float* src = a.field + (size_t)s * a.total + (size_t)(a.ya + y) * a.nx + a.xa;
+    float* box = a.box + ((size_t)s * a.h + y) * a.w;
+    for (uint32_t x = threadIdx.x; x < a.w; x += kBlock) {
+        if (a.back) src[x] = box[x];
+        else box[x] = src[x];
+    }
+}
+
+// maximal runs of set flags -> intervals with one clean element on either side (or the array's end), at least minLen long where
+// the array allows, merged where they overlap by more than a shared boundary
+std::vector<std::pair<uint32_t, uint32_t>> dirty_intervals(const std::vector<unsigned char>& dirty, uint32_t minLen)
+{
+    const uint32_t n = (uint32_t)dirty.size();
+    std::vector<std::pair<uint32_t, uint32_t>> out;
+    for (uint32_t i = 0; i < n;) {
+        if (!dirty[i]) { ++i; continue; }
+        uint32_t j = i;
+        while (j + 1 < n && dirty[j + 1]) ++j;
+        uint32_t a = i > 0 ? i - 1 : 0, b = j + 1 < n ? j + 1 : n - 1;
+        while (b - a + 1 < minLen && (b + 1 < n || a > 0)) {  // grow over clean elements (a later dirty one: merged below)
+            if (b + 1 < n) ++b;
+            else --a;
+        }
+        out.emplace_back(a, b);
+        i = j + 1;
+    }
+    // merge: an interval that reaches into the next one's dirty elements
+    std::vector<std::pair<uint32_t, uint32_t>> merged;
+    for (const auto& iv : out) {
+        if (!merged.empty() && iv.first < merged.back().second) merged.back().second = std::max(merged.back().second, iv.second);
+        else merged.push_back(iv);
+    }
+    // the ends must be clean or the array's ends: growing may have stopped on a dirty element of a neighbour that was merged away
+    for (auto& iv : merged) {
+        while (iv.first > 0 && dirty[iv.first]) --iv.first;
+        while (iv.second + 1 < n && dirty[iv.second]) ++iv.second;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> fin;
+    for (const auto& iv : merged) {
+        if (!fin.empty() && iv.first < fin.back().second) fin.back().second = std::max(fin.back().second, iv.second);
+        else fin.push_back(iv);
+    }
+    return fin;
+}
+
+// Undefined cells inside rectangle r (whose ring is defined, or the field's border) -> the rectangles that hold them: runs of rows
+// with undefined cells x runs of columns with undefined cells in those rows, each looked at again on its own (the rows a column
+// run needs are often fewer than the row run it came from).
+void refine_rect(const uint32_t* bits, uint32_t words, const Rect& r, int depth, std::vector<Rect>& out)
+{
+    const uint32_t w = r.xb - r.xa + 1, h = r.yb - r.ya + 1;
+    const uint32_t k0 = r.xa >> 5, k1 = r.xb >> 5;
+    auto word_mask = [&](uint32_t k) -> uint32_t {
+        uint32_t m = 0xFFFFFFFFu;
+        if (k == k0) m &= 0xFFFFFFFFu << (r.xa & 31);
+        if (k == k1) m &= 0xFFFFFFFFu >> (31 - (r.xb & 31));
+        return m;
+    };
+    std::vector<unsigned char> rowDirty(h, 0);
+    for (uint32_t y = 0; y < h; ++y) {
+        uint32_t any = 0;
+        for (uint32_t k = k0; k <= k1; ++k) any |= bits[(size_t)(r.ya + y) * words + k] & word_mask(k);
+        rowDirty[y] = any != 0;
+    }
+    for (const auto& rv : dirty_intervals(rowDirty, 4)) {
+        std::vector<uint32_t> orw(k1 - k0 + 1, 0);
+        for (uint32_t y = rv.first; y <= rv.second; ++y)
+            for (uint32_t k = k0; k <= k1; ++k) orw[k - k0] |= bits[(size_t)(r.ya + y) * words + k] & word_mask(k);
+        std::vector<unsigned char> colDirty(w, 0);
+        for (uint32_t x = 0; x < w; ++x) { const uint32_t ax = r.xa + x; colDirty[x] = (orw[(ax >> 5) - k0] >> (ax & 31)) & 1u; }
+        for (const auto& cv : dirty_intervals(colDirty, 4)) {
+            const Rect q{r.xa + cv.first, r.xa + cv.second, r.ya + rv.first, r.ya + rv.second};
+            if (q == r || depth == 0) out.push_back(q);
+            else refine_rect(bits, words, q, depth - 1, out);
+        }
+    }
+}
+
+// the rectangles of one slice from its NaN bitmap; false: not worth it, take the whole slice
+bool slice_rects(const uint32_t* bits, uint32_t nx, uint32_t ny, uint32_t words, std::vector<Rect>& rects)
+{
+    rects.clear();
+    refine_rect(bits, words, Rect{0, nx - 1, 0, ny - 1}, 4, rects);
+    size_t area = 0;
+    for (const Rect& r : rects) area += (size_t)(r.xb - r.xa + 1) * (r.yb - r.ya + 1);
+    return !rects.empty() && rects.size() <= 64 && area * 2 <= (size_t)nx * ny;
+}
+
+}  // namespace
+
+void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefault, float defaultVal,
+                   unsigned short repeat, char setWeight, size_t* h_nChanged, hipStream_t stream)
+{
+    if (nx * ny == 0 || nz == 0) return;  // :1380
+    const size_t total = nx * ny;
+    // worth looking for rectangles: large slices (the decomposition costs a pass over the data and a host round trip)
+    if (tuning("CREEP_RECTS", 1) == 0 || nx < 64 || ny < 64 || nx > 0x7FFFFFFFu || ny > 0x7FFFFFFFu || total * nz > ((size_t)1 << 33)) {
+        run_creepfill_whole(nx, ny, nz, d_field, useDefault, defaultVal, repeat, setWeight, h_nChanged, stream, nullptr);
+        return;
+    }
+    const uint32_t words = (uint32_t)(ceil_div(nx, (size_t)64) * 2);
+    DeviceArray<uint32_t> d_bits(nz * ny * words), d_rowCount(nz * ny);
+    nan_bitmap_kernel<<<dim3((uint32_t)ceil_div(nz * ny, (size_t)(kBlock / kWave))), kBlock, 0, stream>>>(d_field, (uint32_t)nx, nz * ny, words, d_bits.get(), d_rowCount.get());
+    FA_HIP(hipGetLastError());
+    // first the rows' counts (a few KB): holes scattered over (nearly) all rows of a slice leave nothing to cut -- the usual case pays a pass
+    // over the data on the device and this copy, not the bitmap's
+    std::vector<uint32_t> rowCount(nz * ny);
+    FA_HIP(hipMemcpyAsync(rowCount.data(), d_rowCount.get(), rowCount.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    bool all = true;
+    size_t withHoles = 0;
+    std::vector<unsigned char> consider(nz, 0);  // slices with undefined AND defined cells (the others are left alone, :1384-1386)
+    for (size_t z = 0; z < nz && all; ++z) {
+        size_t dirtyRows = 0, undefined = 0;
+        for (size_t y = 0; y < ny; ++y) { dirtyRows += rowCount[z * ny + y] != 0; undefined += rowCount[z * ny + y]; }
+        if (undefined == 0 || undefined == total) continue;
+        consider[z] = 1;
+        withHoles++;
+        if (dirtyRows * 10 > ny * 9) all = false;
+    }
+    std::vector<std::vector<Rect>> rects(nz);
+    std::vector<uint32_t> bits;
+    if (all && withHoles != 0) {
+        bits.resize(nz * ny * words);
+        FA_HIP(hipMemcpyAsync(bits.data(), d_bits.get(), bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        FA_HIP(hipStreamSynchronize(stream));
+        for (size_t z = 0; z < nz && all; ++z)
+            if (consider[z]) all = slice_rects(bits.data() + z * ny * words, (uint32_t)nx, (uint32_t)ny, words, rects[z]);
+    }
+    if (!all || withHoles == 0) {
+        FA_REQUIRE(tuning("CREEP_RECTS", 1) != 2 || withHoles == 0, "creepfill: CREEP_RECTS=2 (tests) asks for a field that can be cut into rectangles");
+        run_creepfill_whole(nx, ny, nz, d_field, useDefault, defaultVal, repeat, setWeight, h_nChanged, stream, nullptr);
+        return;
+    }
+    // the whole slices' statistics: the first guess (mean of the defined cells in scan order, :1502-1516) and *nChanged
+    DeviceArray<SliceStats> stats(nz);
+    FA_HIP(hipMemsetAsync(stats.get(), 0, nz * sizeof(SliceStats), stream));
+    {
+        FillStatsArgs fs{};
+        fs.field = d_field;
+        fs.stats = stats.get();
+        fs.total = total;
+        fs.useDefault = useDefault ? 1 : 0;
+        fs.defaultVal = defaultVal;
+        fs.sumAlgo = tuning("SUM_ALGO", 1);
+        if (fs.sumAlgo > 1) fs.sumAlgo = 1;
+        fill_stats_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(fs);
+        FA_HIP(hipGetLastError());
+    }
+    std::vector<SliceStats> h_stats(nz);
+    FA_HIP(hipMemcpyAsync(h_stats.data(), stats.get(), nz * sizeof(SliceStats), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    std::vector<double> defaults(nz);
+    std::vector<unsigned long long> bounds(nz);  // the loop of a rectangle ends where the whole slice's would (:1430)
+    for (size_t z = 0; z < nz; ++z) {
+        if (h_nChanged) h_nChanged[z] = (size_t)h_stats[z].nUndef;
+        defaults[z] = h_stats[z].average;
+        bounds[z] = h_stats[z].sweepBound;
+    }
+    // groups of consecutive slices with the same rectangles (masks usually do not change from slice to slice)
+    for (size_t z0 = 0; z0 < nz;) {
+        size_t z1 = z0 + 1;
+        while (z1 < nz && rects[z1] == rects[z0] && h_stats[z1].skip == h_stats[z0].skip) ++z1;
+        if (!h_stats[z0].skip) {  // (skip: nothing defined or nothing undefined, :1384-1386)
+            const size_t count = z1 - z0;
+            // rectangles of one size go through the sweeps together, as further slices of one run
+            std::vector<char> done(rects[z0].size(), 0);
+            for (size_t i = 0; i < rects[z0].size(); ++i) {
+                if (done[i]) continue;
+                const Rect& r = rects[z0][i];
+                const size_t w = r.xb - r.xa + 1, h = r.yb - r.ya + 1;
+                std::vector<size_t> same;
+                for (size_t j = i; j < rects[z0].size(); ++j) {
+                    const Rect& q = rects[z0][j];
+                    if (!done[j] && q.xb - q.xa + 1 == w && q.yb - q.ya + 1 == h) { same.push_back(j); done[j] = 1; }
+                }
+                const size_t boxes = same.size() * count;
+                FA_REQUIRE(boxes * h <= 0x7FFFFFFFull, "creepfill: too many rows for one copy");
+                DeviceArray<float> box(boxes * w * h);
+                std::vector<double> hd(boxes);
+                std::vector<unsigned long long> hb(boxes);
+                for (size_t k = 0; k < same.size(); ++k)
+                    for (size_t c = 0; c < count; ++c) { hd[k * count + c] = defaults[z0 + c]; hb[k * count + c] = bounds[z0 + c]; }
+                DeviceArray<double> d_def(boxes);
+                DeviceArray<unsigned long long> d_bnd(boxes);
+                FA_HIP(hipMemcpyAsync(d_def.get(), hd.data(), boxes * sizeof(double), hipMemcpyHostToDevice, stream));
+                FA_HIP(hipMemcpyAsync(d_bnd.get(), hb.data(), boxes * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+                auto copy = [&](int back) {
+                    for (size_t k = 0; k < same.size(); ++k) {
+                        const Rect& q = rects[z0][same[k]];
+                        if (kTuningBuild && !back && tuning("CREEP_RECTS", 1) == 3)
+                            fprintf(stderr, "creepfill: slices %zu..%zu rectangle x %u..%u y %u..%u\n", z0, z1 - 1, q.xa, q.xb, q.ya, q.yb);
+                        RectCopyArgs c{d_field + z0 * total, box.get() + k * count * w * h, total, (uint32_t)nx, (uint32_t)w, (uint32_t)h, q.xa, q.ya, back};
+                        rect_copy_kernel<<<dim3((uint32_t)(count * h)), kBlock, 0, stream>>>(c);
+                        FA_HIP(hipGetLastError());
+                    }
+                };
+                copy(0);
+                run_creepfill_whole(w, h, boxes, box.get(), true, 0.f, repeat, setWeight, nullptr, stream, d_def.get(), d_bnd.get());  // synchronises
+                copy(1);
+                FA_HIP(hipStreamSynchronize(stream));  // box, hd, hb are released at the end of the iteration
+            }
+        }
+        z0 = z1;
+    }
+    FA_HIP(hipStreamSynchronize(stream));
 }
 
 void run_scan_sum(const float* d_values, size_t n, int mode, double average, int algo, double* h_sum, size_t* h_nUndefined, hipStream_t stream)

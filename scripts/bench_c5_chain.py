@@ -15,9 +15,12 @@ def main():
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--out", type=int, default=3000, help="target grid: OUT x OUT lat/lon cells over lon -25..25, lat 52..78")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tuning-build", action="store_true")
     a = ap.parse_args()
     import torch
     from fimex_amd import capi as fa
+    if a.tuning_build:
+        fa.use_tuning_build(True)
     fa.load(); fa.set_device(0)
     st = torch.cuda.current_stream().cuda_stream
     n, ox, oy, nz = 3000, a.out, a.out, a.nz

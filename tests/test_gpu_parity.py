@@ -430,6 +430,55 @@ def test_creepfill_both_kernels_agree(fa, monkeypatch, tuning_build):
     assert cases.same(fa.creepfill2d_host(f[:1], 3, 2)[0][0], want)
 
 
+def _patchy_field(nz, ny, nx, seed):
+    """Mostly defined slices with a few undefined regions: what a regridded field looks like (a corner outside the source domain, masked
+    areas), not scattered holes.  Regions: a wedge in the upper left corner that reaches both borders (filled from below and from the
+    right: one row / column per sweep), a block in the middle, two blocks side by side in the same rows, two blocks with exactly one
+    defined row between them, single cells, undefined cells ON the right border column and the bottom row."""
+    rng = np.random.default_rng(seed)
+    f = (280 + 10 * rng.standard_normal((nz, ny, nx))).astype(np.float32)
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    f[:, (yy * 2 + xx) < ny // 3] = np.nan                                  # wedge at the upper left corner
+    f[:, ny // 2: ny // 2 + 23, nx // 3: nx // 3 + 31] = np.nan             # a block
+    f[:, ny // 2 + 40: ny // 2 + 52, 5:17] = np.nan                         # two blocks in the same rows ...
+    f[:, ny // 2 + 41: ny // 2 + 50, nx - 30: nx - 11] = np.nan             # ... far apart in x
+    f[:, ny - 30: ny - 25, 40:60] = np.nan                                  # two blocks, one defined row between them
+    f[:, ny - 24: ny - 20, 45:80] = np.nan
+    f[:, 70, 90] = np.nan
+    f[:, ny // 2 + 5: ny // 2 + 9, nx - 1] = np.nan                         # on the right border
+    f[:, ny - 1, nx // 2: nx // 2 + 6] = np.nan                             # on the bottom row
+    return f
+
+
+@pytest.mark.parametrize("shape", [(230, 170, 3), (301, 260, 2), (96, 400, 2)])
+@pytest.mark.parametrize("params", [(20, 2), (3, 1), (1, 0), (40, 2)])
+def test_creepfill_by_rectangles(fa, monkeypatch, shape, params, tuning_build):
+    """Fields that are defined in most rows and columns are cut along those into rectangles that are filled on their own (rows and
+    columns defined throughout never change and weigh the same as borders or as interior cells).  Same bits as the oracle and as
+    the sweeps over the whole field, for creepfill2d and creepfillval2d; slices with different masks, a slice without undefined
+    cells and one without defined cells in the batch."""
+    nx, ny, nz = shape
+    repeat, weight = params
+    f = _patchy_field(nz + 3, ny, nx, seed=nx + ny + repeat)
+    f[1, 20:30, 100:140 if nx > 140 else 50:90] = np.nan   # slice 1: one region more than its neighbours
+    f[nz] = 281.0                                           # nothing undefined
+    f[nz + 1] = np.nan                                      # nothing defined
+    monkeypatch.setenv("FIMEX_AMD_CREEP_RECTS", "2")   # 2: fails instead of falling back to the whole field
+    got, nch = fa.creepfill2d_host(f, repeat, weight)
+    gotv, nchv = fa.creepfillval2d_host(f, 271.25, repeat, weight)
+    monkeypatch.setenv("FIMEX_AMD_CREEP_RECTS", "0")
+    whole, nchw = fa.creepfill2d_host(f, repeat, weight)
+    assert list(nch) == list(nchw)
+    assert cases.same(got, whole), cases.describe_mismatch(got, whole)
+    for z in range(f.shape[0]):
+        want, wn, rc = oracle.creepfill2d(f[z], repeat, weight)
+        assert rc == oracle.OK and nch[z] == wn
+        assert cases.same(got[z], want), "slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+        wantv, wnv, rc = oracle.creepfillval2d(f[z], 271.25, repeat, weight)
+        assert rc == oracle.OK and nchv[z] == wnv
+        assert cases.same(gotv[z], wantv), "slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))
+
+
 def test_creepfill_negative_weight_takes_the_counter_kernel(fa):
     """a negative setWeight wraps in the reference's size_t sum (interpolation.c:1445); only the counter kernel mirrors that."""
     f = cases.holes(1, 40, 50, seed=5)

@@ -139,7 +139,7 @@ struct FtArgs {
     const uint32_t* chunkOff;
     const unsigned short* steps;
     FtGeom g;
-    uint32_t nOut, inBytes, nz, slotChunks, tableBytes, slots;
+    uint32_t nOut, inBytes, nz, slotChunks, slots;
     uint32_t zStart[kFtMaxZChunks + 1];  // z chunk c = slices zStart[c] .. zStart[c + 1]
     uint32_t loadAux;  // tuning build (FWD_TILED_AUX): cache policy of the staging loads
     uint32_t ablate;  // tuning build (FWD_TILED_ABLATE): 1 = no staging, 2 = no walk
@@ -407,7 +407,7 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
     ft.tilesX = g.tilesX;
     ft.nTiles = g.nTiles;
     ft.slotChunks = (uint32_t)ceil_div((size_t)maxChunks, (size_t)kWave) * kWave;
-    ft.tableBytes = (uint32_t)(ceil_div((size_t)maxLen, (size_t)kFtGroup) * kFtGroup * kWave * 2);
+    ft.groups = (uint32_t)ceil_div((size_t)maxLen, (size_t)kFtGroup);
     ft.stagedTiles = staged;
     ft.directTiles = direct;
     ft.stagedChunks = chunks;
@@ -436,7 +436,6 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.inBytes = (uint32_t)(a.inLayer * sizeof(float));
     a.nz = (uint32_t)nz;
     a.slotChunks = ft.slotChunks;
-    a.tableBytes = ft.tableBytes;
     // slices per pass (see tile_slices): one.  Several (tuning build) were no faster where a slice of a tile is small (1/4-degree
     // targets, 2 KB per slice: 0.69 ms with one or two, 0.71 with four, 0.73 with eight): the staging loads' run length is what
     // bounds those launches, not a wave's wait
@@ -448,7 +447,7 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.ablate = (uint32_t)tuning("FWD_TILED_ABLATE", 0);
     a.loadAux = (uint32_t)tuning("FWD_TILED_AUX", 0);
     const size_t lds = (size_t)slots * slotBytes;
-    const uint32_t groups = ft.tableBytes / (kFtGroup * kWave * 2);  // of the plan's longest bucket
+    const uint32_t groups = ft.groups;  // of the plan's longest bucket
     // z chunks: step table and chunk list are loaded once per (tile, chunk) -- about as many bytes as one slice of the tile -- so
     // chunks are long, many more workgroups than the chip holds at once (1536 with six per CU) all the same, and the LAST chunks
     // (workgroups start in the order of their indices) are short, so that the last round, which few workgroups run, is short too:

@@ -75,7 +75,7 @@ struct ForwardTile {
 };
 struct ForwardTiles {
     bool valid = false;
-    uint32_t tw = 0, th = 0, tilesX = 0, nTiles = 0, slotChunks = 0, tableBytes = 0;
+    uint32_t tw = 0, th = 0, tilesX = 0, nTiles = 0, slotChunks = 0, groups = 0;  // groups: eight-step groups of the longest bucket
     size_t stagedTiles = 0, directTiles = 0, stagedChunks = 0;
     DeviceArray<ForwardTile> tiles;
     DeviceArray<uint32_t> chunkOff;      // source cell index of every 16-byte chunk a tile stages, row by row

@@ -14,6 +14,7 @@
 // reference's order: the same additions / comparisons as forward.hip's reduce_bucket, so results stay bit-identical.
 // Tiles whose buckets are spread too far for LDS (a bucket across the date line, a pole) read from memory as the lane kernels do.
 #include "staged_common.hpp"
+#include "typed_convert.hpp"
 
 #include <vector>
 
@@ -30,6 +31,8 @@ constexpr uint32_t kFtMaxZChunks = 96;
 
 struct FtGeom {
     uint32_t inX, outX, outY, tw, th, tilesX, nTiles;
+    uint32_t cpc;        // cells per 16-byte chunk: 4 (float), 8 or 16 (slices in a 2- or 1-byte stored type)
+    uint32_t cellBytes;  // 16 / cpc
 };
 
 using FtTile = ForwardTile;
@@ -99,11 +102,12 @@ __global__ void __launch_bounds__(kWave) forward_tile_scan(FtGeom g, const uint3
         atomicMax(&rowMax[i], c);
     }
     __syncthreads();
+    const int cmask = (int)g.cpc - 1;
     if (lane == 0) {
         uint32_t acc = 0;
         for (int i = 0; i < nr; ++i) {
             rowChunk[i] = acc;
-            if (rowMax[i] >= 0) acc += (uint32_t)((rowMax[i] - (rowMin[i] & ~3)) / 4 + 1);  // chunks start on multiples of four cells of the slice
+            if (rowMax[i] >= 0) acc += (uint32_t)((rowMax[i] - (rowMin[i] & ~cmask)) / (int)g.cpc + 1);  // chunks start on multiples of cpc cells of the slice
         }
         rowChunk[nr] = acc;
     }
@@ -115,8 +119,8 @@ __global__ void __launch_bounds__(kWave) forward_tile_scan(FtGeom g, const uint3
     }
     for (int i = 0; i < nr; ++i) {  // the chunk list: source cell index of every chunk's first cell
         if (rowMax[i] < 0) continue;
-        const uint32_t first = (uint32_t)(rowMin[i] & ~3), n = rowChunk[i + 1] - rowChunk[i];
-        for (uint32_t k = lane; k < n; k += kWave) chunkOff[T.chunkBase + rowChunk[i] + k] = first + 4u * k;
+        const uint32_t first = (uint32_t)(rowMin[i] & ~cmask), n = rowChunk[i + 1] - rowChunk[i];
+        for (uint32_t k = lane; k < n; k += kWave) chunkOff[T.chunkBase + rowChunk[i] + k] = first + g.cpc * k;
     }
     const uint32_t padded = (T.maxLen + kFtGroup - 1) / kFtGroup * kFtGroup;
     for (uint32_t s = 0; s < padded; ++s) {  // the step table: LDS position (in bytes) of step s of every lane's bucket; past its end: the padding cell
@@ -124,15 +128,18 @@ __global__ void __launch_bounds__(kWave) forward_tile_scan(FtGeom g, const uint3
         if (b + s < e) {
             const int c = (int)src[b + s];
             const int i = c / (int)g.inX - rmin;
-            v = (rowChunk[i] * 4u + (uint32_t)(c - (rowMin[i] & ~3))) * 4u;
+            v = (rowChunk[i] * g.cpc + (uint32_t)(c - (rowMin[i] & ~cmask))) * g.cellBytes;
         }
         steps[(size_t)T.stepBase + step_entry(s, lane)] = (unsigned short)v;
     }
 }
 
 struct FtArgs {
-    const float* in;
-    float* out;
+    const void* in;   // elements of T: float, or the variable's 1- or 2-byte stored type
+    void* out;
+    float bad;        // stored types: the fill value narrowed to float (mifi_bad2nanf's parameter), whether there is one,
+    int hasBad;       // and the fill value as interpolationArray2Data receives it
+    double fillOut;
     const uint32_t* offsets;
     const uint32_t* src;
     const FtTile* tiles;
@@ -189,11 +196,33 @@ __device__ __forceinline__ void take_plain(float v, float& acc, uint32_t& cnt)
     }
 }
 
-// Slices z0 .. z1 of one tile, by one wave.
-template <int KIND, bool UNDEF, int G, int KMAX>
+// element of a slice as float: Data::asFloat + mifi_bad2nanf for the stored types (typed_convert.hpp)
+template <typename T>
+__device__ __forceinline__ float cell_value(T raw, float bad, bool hasBad)
+{
+    if constexpr (std::is_same<T, float>::value) return raw;
+    else return as_float_nan(raw, bad, hasBad);
+}
+// a result in the slices' element type: interpolationArray2Data (NaN -> fill value, rounded) for the stored types
+template <typename T>
+__device__ __forceinline__ void store_result(T* p, float r, T fill)
+{
+    if constexpr (std::is_same<T, float>::value) __builtin_nontemporal_store(r, p);
+    else *p = from_float_fill<T>(r, fill);
+}
+
+// Slices z0 .. z1 of one tile, by one wave.  E: the slices' element type.  Stored types have no element that stands for "leaves
+// the result alone" (see take), so their steps past a bucket's end are replaced by that value after the conversion.
+template <int KIND, bool UNDEF, int G, int KMAX, typename E>
 __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint32_t z0, uint32_t z1)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // the workgroup's dynamic LDS
+    constexpr bool kTyped = !std::is_same<E, float>::value;
+    const char* const inBase = reinterpret_cast<const char*>(a.in);
+    E* const outBase = reinterpret_cast<E*>(a.out);
+    const size_t sliceBytes = a.inLayer * sizeof(E);
+    const bool hasBad = a.hasBad != 0;
+    const E fill = kTyped ? static_cast<E>(a.fillOut) : E();  // ScaleValue's newFill_ (include/fimex/Utils.h:456)
     const uint32_t lane = threadIdx.x;
     const FtTile T = a.tiles[tile];
     const uint32_t tx = (tile % a.g.tilesX) * a.g.tw + lane % a.g.tw, ty = (tile / a.g.tilesX) * a.g.th + lane / a.g.tw;
@@ -203,16 +232,16 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
     if (mine) { b = a.offsets[t]; e = a.offsets[t + 1]; }
     const uint32_t len = e - b;
     if (T.maxLen == 0) {
-        if (mine) for (uint32_t z = z0; z < z1; ++z) __builtin_nontemporal_store(undefined_f(), a.out + (size_t)z * a.nOut + t);
+        if (mine) for (uint32_t z = z0; z < z1; ++z) store_result<E>(outBase + (size_t)z * a.nOut + t, undefined_f(), fill);
         return;
     }
     if (T.nChunks == kFtDirect) {  // buckets spread too far for LDS: from memory, slice by slice
         if (mine) for (uint32_t z = z0; z < z1; ++z) {
-            const float* s = a.in + (size_t)z * a.inLayer;
+            const E* s = reinterpret_cast<const E*>(inBase + (size_t)z * sliceBytes);
             float acc = 0.f;
             uint32_t cnt = 0;
-            for (uint32_t j = b; j < e; ++j) take_plain<KIND, UNDEF>(s[a.src[j]], acc, cnt);
-            __builtin_nontemporal_store(cnt == 0 ? undefined_f() : (KIND == 1 ? acc / (float)cnt : acc), a.out + (size_t)z * a.nOut + t);
+            for (uint32_t j = b; j < e; ++j) take_plain<KIND, UNDEF>(cell_value<E>(s[a.src[j]], a.bad, hasBad), acc, cnt);
+            store_result<E>(outBase + (size_t)z * a.nOut + t, cnt == 0 ? undefined_f() : (KIND == 1 ? acc / (float)cnt : acc), fill);
         }
         return;
     }
@@ -240,11 +269,11 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
 #pragma unroll
     for (uint32_t j = 0; j < (uint32_t)KMAX; ++j) {
         const uint32_t c = lane + j * kWave;
-        gOff[j] = a.chunkOff[T.chunkBase + min(c, T.nChunks - 1)] * 4u;
+        gOff[j] = a.chunkOff[T.chunkBase + min(c, T.nChunks - 1)] * (uint32_t)sizeof(E);
     }
     const uint32_t un = (T.nChunks + kWave - 1) / kWave;
     auto dma = [&](uint32_t slot, uint32_t z) __attribute__((always_inline)) {
-        const rsrc_t rs = make_rsrc(a.in + (size_t)z * a.inLayer, a.inBytes);
+        const rsrc_t rs = make_rsrc(inBase + (size_t)z * sliceBytes, a.inBytes);
         float* const dst = &smem[slot * slotFloats];
         uint32_t n = (kTuningBuild && (a.ablate & 1)) ? 0u : un;
         asm volatile("" : "+s"(n));  // compared afresh: hoisted out of the slice loop the 32 conditions cost 64 scalar registers
@@ -274,13 +303,18 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
             auto values = [&](int k, float (&v)[kFtGroup]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[2 * i] = *reinterpret_cast<const float*>(cur + (tr[4 * k + i] & 0xFFFFu));
-                    v[2 * i + 1] = *reinterpret_cast<const float*>(cur + (tr[4 * k + i] >> 16));
+                    v[2 * i] = cell_value<E>(*reinterpret_cast<const E*>(cur + (tr[4 * k + i] & 0xFFFFu)), a.bad, hasBad);
+                    v[2 * i + 1] = cell_value<E>(*reinterpret_cast<const E*>(cur + (tr[4 * k + i] >> 16)), a.bad, hasBad);
+                }
+                if constexpr (kTyped) {
+#pragma unroll
+                    for (int i = 0; i < (int)kFtGroup; ++i)
+                        v[i] = ((uint32_t)(k * (int)kFtGroup + i) < len) ? v[i] : padding_value<KIND, UNDEF>();
                 }
             };
             float v[kFtGroup], vn[kFtGroup];
             values(0, v);
-            const bool firstNan = v[0] != v[0];
+            const bool firstNan = len != 0 && v[0] != v[0];
             const uint32_t walk = (kTuningBuild && (a.ablate & 2)) ? 0u : groups;
 #pragma unroll
             for (int k = 0; k < G; ++k) {
@@ -292,7 +326,7 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
                     for (uint32_t i = 0; i < kFtGroup; ++i) v[i] = vn[i];
                 }
             }
-            if (mine) __builtin_nontemporal_store(finish<KIND, UNDEF>(acc, cnt, len, firstNan), a.out + (size_t)z * a.nOut + t);
+            if (mine) store_result<E>(outBase + (size_t)z * a.nOut + t, finish<KIND, UNDEF>(acc, cnt, len, firstNan), fill);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the reads of this pass are done before the next one overwrites the slots
         asm volatile("" ::: "memory");
@@ -305,13 +339,13 @@ __device__ __forceinline__ void tile_slices(const FtArgs& a, uint32_t tile, uint
 // (Measured against it: as many waves as the chip holds, each with an equal run of (tile, slice) pairs -- no last round for a few
 // tiles, but all waves of a CU then stage and walk in step, 0.66 ms against 0.57 for the dense case of DESIGN.md 6; workgroups that
 // start whenever one ends keep the phases apart.)
-template <int KIND, bool UNDEF, int G, int KMAX>
+template <int KIND, bool UNDEF, int G, int KMAX, typename T = float>
 __global__ void __launch_bounds__(kWave) forward_apply_tiled(FtArgs a)
 {
     const uint32_t perXcd = gridDim.x / kXcds;
     const uint32_t tile = (blockIdx.x % kXcds) * perXcd + blockIdx.x / kXcds;
     if (tile >= a.g.nTiles) return;
-    tile_slices<KIND, UNDEF, G, KMAX>(a, tile, a.zStart[blockIdx.y], a.zStart[blockIdx.y + 1]);
+    tile_slices<KIND, UNDEF, G, KMAX, T>(a, tile, a.zStart[blockIdx.y], a.zStart[blockIdx.y + 1]);
 }
 
 // G groups of eight steps in registers, KMAX chunks per lane and slice: the smallest form that holds the plan's longest bucket and
@@ -326,14 +360,39 @@ void launch_tiled(const FtArgs& a, uint32_t groups, dim3 grid, size_t lds, hipSt
     else if (groups <= 16) forward_apply_tiled<KIND, UNDEF, 16, 32><<<grid, kWave, lds, stream>>>(a);
     else forward_apply_tiled<KIND, UNDEF, 32, 32><<<grid, kWave, lds, stream>>>(a);
 }
+// stored types: three forms
+template <int KIND, bool UNDEF, typename T>
+void launch_tiled_typed(const FtArgs& a, uint32_t groups, dim3 grid, size_t lds, hipStream_t stream)
+{
+    const uint32_t kmax = a.slotChunks / kWave;
+    if (groups <= 4 && kmax <= 8) forward_apply_tiled<KIND, UNDEF, 4, 8, T><<<grid, kWave, lds, stream>>>(a);
+    else if (groups <= 16) forward_apply_tiled<KIND, UNDEF, 16, 32, T><<<grid, kWave, lds, stream>>>(a);
+    else forward_apply_tiled<KIND, UNDEF, 32, 32, T><<<grid, kWave, lds, stream>>>(a);
+}
+template <typename T>
+bool launch_tiled_typed_kind(const fimex_amd_regrid_plan& plan, const FtArgs& a, uint32_t groups, dim3 grid, size_t lds, hipStream_t stream)
+{
+    const bool u = plan.undefAggr;
+    switch (plan.aggregate) {
+    case Aggregate::Sum: u ? launch_tiled_typed<0, true, T>(a, groups, grid, lds, stream) : launch_tiled_typed<0, false, T>(a, groups, grid, lds, stream); break;
+    case Aggregate::Mean: u ? launch_tiled_typed<1, true, T>(a, groups, grid, lds, stream) : launch_tiled_typed<1, false, T>(a, groups, grid, lds, stream); break;
+    case Aggregate::Max: u ? launch_tiled_typed<3, true, T>(a, groups, grid, lds, stream) : launch_tiled_typed<3, false, T>(a, groups, grid, lds, stream); break;
+    case Aggregate::Min: u ? launch_tiled_typed<4, true, T>(a, groups, grid, lds, stream) : launch_tiled_typed<4, false, T>(a, groups, grid, lds, stream); break;
+    default: return false;
+    }
+    return true;
+}
 
 }  // namespace
 
-// The tiled form of a forward plan (after the CSR): built where the buckets are long on average.
-void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
+namespace {
+
+// The tiled form of a forward plan (after the CSR) for slices of cellBytes-byte elements: built where the buckets are long on average.
+void build_tiles(const fimex_amd_regrid_plan& plan, ForwardTiles& ft, uint32_t cellBytes, size_t& planBytes, hipStream_t stream)
 {
-    ForwardTiles& ft = plan.fwdTiles;
     ft.valid = false;
+    ft.cellBytes = cellBytes;
+    planBytes = 0;
     const size_t nOut = plan.outX * plan.outY;
     const size_t nonEmpty = nOut - plan.info.undefinedCells;
     const double meanBucket = nonEmpty ? (double)plan.info.mappedSourceCells / (double)nonEmpty : 0.0;
@@ -362,6 +421,8 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
         c.outY = (uint32_t)plan.outY;
         c.tw = tw;
         c.th = kWave / tw;
+        c.cpc = 16u / cellBytes;
+        c.cellBytes = cellBytes;
         c.tilesX = (uint32_t)ceil_div(plan.outX, (size_t)c.tw);
         const size_t n = (size_t)c.tilesX * ceil_div(plan.outY, (size_t)c.th);
         if (n > 0x7FFFFFFFu / 64) continue;
@@ -412,17 +473,14 @@ void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
     ft.directTiles = direct;
     ft.stagedChunks = chunks;
     ft.valid = true;
-    plan.info.stagedCells = chunks * 4;
-    plan.info.tileW = g.tw;
-    plan.info.tileH = g.th;
-    plan.info.planBytes += nTiles * sizeof(FtTile) + chunks * sizeof(uint32_t) + stepEntries * sizeof(unsigned short);
+    planBytes = nTiles * sizeof(FtTile) + chunks * sizeof(uint32_t) + stepEntries * sizeof(unsigned short);
 }
 
-bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+// everything of a launch but the element type
+bool prepare_launch(const fimex_amd_regrid_plan& plan, const ForwardTiles& ft, const void* d_in, size_t nz, void* d_out, FtArgs& a, dim3& grid,
+                    size_t& lds)
 {
-    const ForwardTiles& ft = plan.fwdTiles;
     if (!ft.valid || plan.aggregate == Aggregate::Median || tuning("FWD_TILED", 1) == 0) return false;
-    FtArgs a{};
     a.in = d_in;
     a.out = d_out;
     a.offsets = plan.offsets.get();
@@ -430,10 +488,10 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.tiles = ft.tiles.get();
     a.chunkOff = ft.chunkOff.get();
     a.steps = ft.steps.get();
-    a.g = FtGeom{(uint32_t)plan.inX, (uint32_t)plan.outX, (uint32_t)plan.outY, ft.tw, ft.th, ft.tilesX, ft.nTiles};
+    a.g = FtGeom{(uint32_t)plan.inX, (uint32_t)plan.outX, (uint32_t)plan.outY, ft.tw, ft.th, ft.tilesX, ft.nTiles, 16u / ft.cellBytes, ft.cellBytes};
     a.nOut = (uint32_t)(plan.outX * plan.outY);
     a.inLayer = plan.inX * plan.inY;
-    a.inBytes = (uint32_t)(a.inLayer * sizeof(float));
+    a.inBytes = (uint32_t)(a.inLayer * ft.cellBytes);
     a.nz = (uint32_t)nz;
     a.slotChunks = ft.slotChunks;
     // slices per pass (see tile_slices): one.  Several (tuning build) were no faster where a slice of a tile is small (1/4-degree
@@ -446,8 +504,7 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
     a.slots = (uint32_t)slots;
     a.ablate = (uint32_t)tuning("FWD_TILED_ABLATE", 0);
     a.loadAux = (uint32_t)tuning("FWD_TILED_AUX", 0);
-    const size_t lds = (size_t)slots * slotBytes;
-    const uint32_t groups = ft.groups;  // of the plan's longest bucket
+    lds = (size_t)slots * slotBytes;
     // z chunks: step table and chunk list are loaded once per (tile, chunk) -- about as many bytes as one slice of the tile -- so
     // chunks are long, many more workgroups than the chip holds at once (1536 with six per CU) all the same, and the LAST chunks
     // (workgroups start in the order of their indices) are short, so that the last round, which few workgroups run, is short too:
@@ -466,7 +523,31 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
             a.zStart[++chunks] = (uint32_t)z;
         }
     }
-    const dim3 grid((uint32_t)(ceil_div((size_t)ft.nTiles, (size_t)kXcds) * kXcds), (uint32_t)chunks, 1);
+    grid = dim3((uint32_t)(ceil_div((size_t)ft.nTiles, (size_t)kXcds) * kXcds), (uint32_t)chunks, 1);
+    return true;
+}
+
+}  // namespace
+
+void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream)
+{
+    size_t bytes = 0;
+    build_tiles(plan, plan.fwdTiles, 4, bytes, stream);
+    if (!plan.fwdTiles.valid) return;
+    plan.info.stagedCells = plan.fwdTiles.stagedChunks * 4;
+    plan.info.tileW = plan.fwdTiles.tw;
+    plan.info.tileH = plan.fwdTiles.th;
+    plan.info.planBytes += bytes;
+}
+
+bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream)
+{
+    const ForwardTiles& ft = plan.fwdTiles;
+    FtArgs a{};
+    dim3 grid;
+    size_t lds = 0;
+    if (!prepare_launch(plan, ft, d_in, nz, d_out, a, grid, lds)) return false;
+    const uint32_t groups = ft.groups;  // of the plan's longest bucket
     const bool u = plan.undefAggr;
     switch (plan.aggregate) {
     case Aggregate::Sum: u ? launch_tiled<0, true>(a, groups, grid, lds, stream) : launch_tiled<0, false>(a, groups, grid, lds, stream); break;
@@ -477,6 +558,51 @@ bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, 
     }
     FA_HIP(hipGetLastError());
     return true;
+}
+
+// Slices in a 1- or 2-byte stored type through the same kernel: half or a quarter of the bytes are staged, elements
+// become floats as they are read from LDS (data2InterpolationArray) and results elements as they are stored
+// (interpolationArray2Data).  The plan's tiled form for that element size is built on the first such call, under the mutex
+// (plans are shared by threads).  false: not this path (the caller converts, applies, converts back).
+bool launch_forward_tiled_typed(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                                hipStream_t stream)
+{
+    if (plan.kind != PlanKind::Forward || plan.aggregate == Aggregate::Median || !plan.fwdTiles.valid || tuning("TYPED_FORWARD", 1) == 0) return false;
+    uint32_t eb = 0;
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: case FIMEX_AMD_CDM_UCHAR: eb = 1; break;
+    case FIMEX_AMD_CDM_SHORT: case FIMEX_AMD_CDM_USHORT: eb = 2; break;
+    default: return false;
+    }
+    if (nz == 0) return true;
+    auto& forms = plan.fwdTyped;
+    ForwardTiles* ft = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(forms.mtx);
+        const int k = eb == 2 ? 0 : 1;
+        if (!forms.tried[k]) {
+            size_t bytes = 0;
+            build_tiles(plan, forms.form[k], eb, bytes, stream);
+            forms.tried[k] = true;
+        }
+        ft = &forms.form[k];
+    }
+    FtArgs a{};
+    dim3 grid;
+    size_t lds = 0;
+    if (!prepare_launch(plan, *ft, d_in, nz, d_out, a, grid, lds)) return false;
+    a.bad = (float)badValue;
+    a.hasBad = !(a.bad != a.bad);
+    a.fillOut = badValue;
+    bool ok = false;
+    switch (cdmType) {
+    case FIMEX_AMD_CDM_CHAR: ok = launch_tiled_typed_kind<signed char>(plan, a, ft->groups, grid, lds, stream); break;
+    case FIMEX_AMD_CDM_UCHAR: ok = launch_tiled_typed_kind<unsigned char>(plan, a, ft->groups, grid, lds, stream); break;
+    case FIMEX_AMD_CDM_SHORT: ok = launch_tiled_typed_kind<short>(plan, a, ft->groups, grid, lds, stream); break;
+    default: ok = launch_tiled_typed_kind<unsigned short>(plan, a, ft->groups, grid, lds, stream); break;
+    }
+    FA_HIP(hipGetLastError());
+    return ok;
 }
 
 }  // namespace fimex_amd

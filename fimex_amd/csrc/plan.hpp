@@ -76,6 +76,7 @@ struct ForwardTile {
 struct ForwardTiles {
     bool valid = false;
     uint32_t tw = 0, th = 0, tilesX = 0, nTiles = 0, slotChunks = 0, groups = 0;  // groups: eight-step groups of the longest bucket
+    uint32_t cellBytes = 4;  // element size of the slices this form stages: 4 (float), 2 or 1 (stored types)
     size_t stagedTiles = 0, directTiles = 0, stagedChunks = 0;
     DeviceArray<ForwardTile> tiles;
     DeviceArray<uint32_t> chunkOff;      // source cell index of every 16-byte chunk a tile stages, row by row
@@ -118,6 +119,13 @@ struct fimex_amd_regrid_plan {
     bool undefAggr = false;
     fimex_amd::DeviceArray<uint32_t> offsets, src;
     fimex_amd::ForwardTiles fwdTiles;
+    // the same for slices of 2- and 1-byte stored types, built on the first typed apply of that element size (see TypedForms)
+    struct FwdTypedForms {
+        std::mutex mtx;
+        bool tried[2] = {false, false};
+        fimex_amd::ForwardTiles form[2];
+    };
+    mutable FwdTypedForms fwdTyped;
 
     fimex_amd_plan_info info{};
 };
@@ -155,6 +163,8 @@ void launch_forward_apply(const fimex_amd_regrid_plan& plan, const float* d_in, 
 // forward_tiled.hip
 void build_forward_tiles(fimex_amd_regrid_plan& plan, hipStream_t stream);
 bool launch_forward_tiled(const fimex_amd_regrid_plan& plan, const float* d_in, size_t nz, float* d_out, hipStream_t stream);
+bool launch_forward_tiled_typed(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
+                                hipStream_t stream);
 
 // vector.hip
 void build_vector_plan(fimex_amd_vector_plan& plan, const double* h_matrix);

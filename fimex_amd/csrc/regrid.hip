@@ -760,6 +760,8 @@ void launch_backward_gather(const fimex_amd_regrid_plan& plan, const float* d_in
 bool launch_typed_apply(const fimex_amd_regrid_plan& plan, const void* d_in, int cdmType, size_t nz, double badValue, void* d_out,
                         hipStream_t stream)
 {
+    // forward plans with long buckets: the LDS-staged forward kernel on the stored type (forward_tiled.hip)
+    if (plan.kind == PlanKind::Forward) return launch_forward_tiled_typed(plan, d_in, cdmType, nz, badValue, d_out, stream);
     // 1- and 2-byte types through the LDS-staged kernels (the same dispatch rule as for floats): the second staged form
     // (staged2.hip, nearest and bilinear), else the first one
     if (plan.kind != PlanKind::Forward && tuning("TYPED_FUSED", 1) != 0 && tuning("STAGED", 1) != 0 && tuning("TYPED_STAGED", 1) != 0 &&

@@ -83,6 +83,27 @@ def main():
                  kernel_pattern="forward_apply", bytes_survey_8d=nz * 4 * (fw.inX * fw.inY + ox * oy) + info["planBytes"], cells=nz * fw.inX * fw.inY,
                  mapped_source_cells=info["mappedSourceCells"], plan_bytes=info["planBytes"], staged_cells_per_slice=info["stagedCells"], tile=[info["tileW"], info["tileH"]])
         r["bytes_must_move"] = r["bytes_survey_8d"]
+    elif a.case.startswith("typedforward"):
+        # typedforward<k>_<aggregate>: the dense forward mapping onto 1/k degree on PACKED SHORTS (SURVEY 8f n1 x a7)
+        fw = workloads.ForwardLambert()
+        head, aggr = a.case.split("_")
+        k = int(head[len("typedforward"):] or 1)
+        ox, oy = 360 * k, 180 * k
+        tx = (np.arange(ox) + 0.5) / k - 180.0; ty = (np.arange(oy) + 0.5) / k - 90.0
+        lon, lat = np.meshgrid(fw.src_lon, fw.src_lat)
+        px = workloads.axis_positions_numpy(lon.ravel(), tx); py = workloads.axis_positions_numpy(lat.ravel(), ty)
+        m = {"mean": fa.FORWARD_MEAN, "max": fa.FORWARD_MAX, "sum": fa.FORWARD_SUM}[aggr]
+        nz = 100
+        d_in = bench.make_slices(torch, fw.base_field(), nz)
+        d_s = ((d_in - 280) * 100).nan_to_num(-32767).to(torch.int16)
+        del d_in
+        d_o = torch.empty((nz, oy, ox), dtype=torch.int16, device="cuda")
+        plan = fa.RegridPlan(m, px, py, fw.inX, fw.inY, ox, oy)
+        info = plan.info()
+        ts = timed(lambda: fa.regrid_apply_typed_device(plan, d_s.data_ptr(), fa.CDM_SHORT, nz, -32767.0, d_o.data_ptr(), st))
+        r.update(workload="0.1-degree global 3600x1800 packed shorts -> 1/%d-degree global %dx%d, forward, %d slices, %d source cells per bucket at most" % (k, ox, oy, nz, info["maxBucket"]),
+                 kernel_pattern="forward_apply", bytes_survey_8d=nz * 2 * (fw.inX * fw.inY + ox * oy) + info["planBytes"], cells=nz * fw.inX * fw.inY)
+        r["bytes_must_move"] = r["bytes_survey_8d"]
     elif a.case in ("rotate_values", "rotate_direction"):
         wl = workloads.BilinearRotatedPole()
         nz, n = 200, wl.outX * wl.outY

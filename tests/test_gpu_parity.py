@@ -948,6 +948,39 @@ def test_regrid_on_the_stored_type_device_resident(fa, monkeypatch, method, dt, 
         assert np.array_equal(results[-1].view(np.uint8), want.view(np.uint8)), (staged, fused, np.dtype(dt).name)
 
 
+@pytest.mark.parametrize("method", [oracle.FWD_MEAN, oracle.FWD_UNDEF_MEAN, oracle.FWD_SUM, oracle.FWD_MAX, oracle.FWD_UNDEF_MIN, oracle.FWD_MEDIAN])
+@pytest.mark.parametrize("dt,bad", [(np.int16, -32767.0), (np.uint16, 65535.0), (np.int8, -127.0), (np.uint8, 255.0), (np.int16, float("nan")), (np.int32, -2147483647.0)])
+@pytest.mark.parametrize("shape,density", [((400, 300, 37, 29), 1.5), ((333, 377, 32, 80), 1.3), ((257, 129, 64, 33), 0.9)])
+def test_forward_on_the_stored_type(fa, monkeypatch, method, dt, bad, shape, density, tuning_build):
+    """fimex_amd_regrid_apply_typed_device on forward plans with long buckets: the LDS-staged forward kernel reads the slices in
+    their 1- or 2-byte stored type (a tiled form of the plan with 8 or 16 cells per 16-byte chunk, built on the first such call)
+    and writes results in that type; wider types, medians and TYPED_FORWARD=0 take the three passes.  All against the oracle's three
+    steps (data2InterpolationArray, interpolateValues, interpolationArray2Data); with and without a fill value; buckets that hold
+    nothing but fill values; sums that leave the type's range (the reference's casts wrap)."""
+    import torch
+    inX, inY, outX, outY = shape
+    nz = 11
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=41, density=density, special=False)
+    rng = np.random.default_rng(5)
+    info = np.iinfo(dt)
+    f = rng.integers(max(info.min, -3000) // 2, min(info.max, 3000) // 2 + 1, (nz, inY, inX)).astype(dt)
+    if bad == bad:
+        f.reshape(-1)[rng.choice(f.size, f.size // 20, replace=False)] = dt(bad)
+        f[:, 40:90, 100:180] = dt(bad)     # whole buckets of fill values
+    code = oracle.cdm_type_of(dt)
+    want = oracle.interpolation_array2data(
+        oracle.forward_interpolate_values(method, px, py, oracle.data2interpolation_array(f, bad), inX, inY, outX, outY), code, bad)
+    plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+    t = torch.from_numpy(f.view(np.uint8)).cuda()
+    for fused in ("1", "0"):
+        monkeypatch.setenv("FIMEX_AMD_TYPED_FORWARD", fused)
+        out = torch.zeros(nz * outY * outX * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+        fa.regrid_apply_typed_device(plan, t.data_ptr(), code, nz, bad, out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(dt).reshape(want.shape)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (fused, np.dtype(dt).name, int((got != want).sum()))
+
+
 @pytest.mark.parametrize("shape", [(400, 300, 200, 200), (403, 301, 130, 77), (1200, 900, 600, 500)])
 def test_bicubic_fast_arithmetic_within_the_stated_tolerance(fa, shape):
     """FIMEX_AMD_BICUBIC_FAST (float fused multiply-adds, include/fimex_amd.h) against the oracle's reference arithmetic

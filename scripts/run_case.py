@@ -130,11 +130,11 @@ def main():
             ts = timed(lambda: fa.creepfill2d_device(d.data_ptr(), nx, ny, nz, 20, 2, st), reset)
             r.update(workload="mifi_creepfill2d_f(repeat 20, setWeight 2) on %d slices of 3000x3000, 30 %% holes" % nz, kernel_pattern="fill")
         r.update(cells=nz * nx * ny, bytes_survey_8d=None, bytes_must_move=None, note="iteration dependent: time and sweeps, no roofline claim (SURVEY 8d)")
-    elif a.case in ("bilinear_short", "bicubic_short", "bicubicfast_short", "typed_short_bilinear", "typed_short_nearest", "typed_uchar_bilinear", "typed_short_bilinear_short"):
+    elif a.case in ("bilinear_short", "bicubic_short", "bicubicfast_short", "typed_short_bilinear", "typed_short_nearest", "typed_uchar_bilinear", "typed_short_bilinear_short", "typed_short_bicubic"):
         wl = workloads.BilinearRotatedPole()
         typed = a.case.startswith("typed_")
         nz = 200 if (typed and not a.case.endswith("_short")) else 25
-        method = fa.BICUBIC if a.case.startswith("bicubic") else (fa.NEAREST_NEIGHBOR if a.case.endswith("nearest") else fa.BILINEAR)
+        method = fa.BICUBIC if (a.case.startswith("bicubic") or a.case.endswith("bicubic")) else (fa.NEAREST_NEIGHBOR if a.case.endswith("nearest") else fa.BILINEAR)
         plan, px, py = bench.build_plan(fa, torch, wl, method, st, bicubic=fa.BICUBIC_FAST if a.case == "bicubicfast_short" else None)
         info = plan.info()
         d_in = bench.make_slices(torch, wl.base_field(), nz)
@@ -148,7 +148,7 @@ def main():
             del d_in
             ts = timed(lambda: fa.regrid_apply_typed_device(plan, d_s.data_ptr(), code, nz, bad, d_o.data_ptr(), st))
             # the plan bytes of the stored-type form: LDS offsets (4 B) and the two fractions (8 B) per cell, the chunk lists are small
-            plan_bytes = (12 if method == fa.BILINEAR else 4) * out
+            plan_bytes = (12 if method == fa.BILINEAR else (24 if method == fa.BICUBIC else 4)) * out
             r.update(workload="%s, %d slices, %s, fused conversion (SURVEY 8f n1)" % ("packed shorts" if eb == 2 else "unsigned bytes", nz, a.case.split("_")[2]),
                      kernel_pattern="_apply", bytes_survey_8d=nz * eb * (wl.inX * wl.inY + out) + plan_bytes)
         else:

@@ -697,6 +697,7 @@ struct FillStatsArgs {
     int sumAlgo;
     const double* defaults;  // per slice, instead of defaultVal (the rectangles of a decomposed creep fill: the whole slice's average)
     const unsigned long long* bounds;  // per slice, with defaults: SliceStats::sweepBound
+    const double* devs;                // per slice, with defaults: SliceStats::meanAbsDev (fill2d by rectangles: the whole field's criterion)
 };
 
 __global__ void __launch_bounds__(kFillBlock) fill_stats_kernel(FillStatsArgs a)
@@ -721,6 +722,7 @@ __global__ void __launch_bounds__(kFillBlock) fill_stats_kernel(FillStatsArgs a)
     __syncthreads();
     nUndef = shUndef;
     const unsigned long long nDef = a.total - nUndef;
+    if (a.devs) { if (threadIdx.x == 0) st->meanAbsDev = a.devs[blockIdx.x]; return; }
     if (!a.wantDeviation || nDef == 0 || nUndef == 0) return;
     const double dev = scan_order_sum(f, a.total, 1, shAverage, lds, nullptr, a.sumAlgo);
     if (threadIdx.x == 0) st->meanAbsDev = (double)a.relaxCrit * (dev / (double)nDef);  // :1302
@@ -794,11 +796,13 @@ __global__ void __launch_bounds__(kBlock) first_guess_kernel(FirstGuessArgs a)
 
 void launch_fill_prologue(bool creep, float* d_field, SliceStats* d_stats, size_t nx, size_t ny, size_t nz, uint32_t* mask, uint32_t mws,
                           unsigned char* mbRows, unsigned char* mbCols, bool wantDeviation, bool useDefault, float defaultVal, float relaxCrit,
-                          hipStream_t stream, const double* d_defaults = nullptr, const unsigned long long* d_bounds = nullptr)
+                          hipStream_t stream, const double* d_defaults = nullptr, const unsigned long long* d_bounds = nullptr,
+                          const double* d_devs = nullptr)
 {
     FillStatsArgs s{};
     s.defaults = d_defaults;
     s.bounds = d_bounds;
+    s.devs = d_devs;
     s.field = d_field;
     s.stats = d_stats;
     s.total = nx * ny;
@@ -865,6 +869,9 @@ struct Fill2dV2Args {
     uint32_t syncStride, groups, nz;
     uint32_t experiment;
     unsigned long long* prof;
+    // > 0 (fill2d by rectangles): slices i, i + couple, i + 2 couple, ... are rectangles of ONE field and end their sweeps together,
+    // by the criterion over all of them (:1338-1359); word [3] of slice i % couple's sync words is their barrier counter
+    uint32_t couple;
 };
 
 // Flags of the LDS hand-off.  The LDS executes one wave's operations in issue order and is coherent within the CU, so a
@@ -1489,7 +1496,10 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v3(Fill2dV2Args a
     const uint32_t nxm1 = nx - 1, nym1 = ny - 1;
     const uint32_t nBands = (ny - 2 + kWave - 1) / kWave;
     float* ring = rings + wave * (kWave + 1) * kPitch;
-    unsigned int barriers = 0, checks = 0;
+    unsigned int barriers = 0, checks = 0, groupBarriers = 0;
+    const uint32_t leader = a.couple ? slice % a.couple : slice;
+    const uint32_t members = a.couple ? a.nz / a.couple : 1u;
+    unsigned int* lsync = a.sync + (size_t)leader * a.syncStride;
     for (unsigned long long n = 0; n < a.maxLoop; ++n) {
         const bool check = (n < (a.maxLoop - 5)) && (n % 10 == 0);
         int bad = 0;
@@ -1498,16 +1508,24 @@ __global__ void __launch_bounds__(WAVES * kWave) fill2d_kernel_v3(Fill2dV2Args a
         for (uint32_t b = g * kV2Waves + wave; b < nBands; b += G * kV2Waves)
             if (check) fill2d_band<CH, WAVES, true, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad, mg);
             else fill2d_band<CH, WAVES, false, true>(f, maskS, ring, hand, b, nx, ny, mws, wInt, wZero, crtest, bad, mg);
-        unsigned int* notConverged = sync + 1 + (checks & 1);
+        unsigned int* notConverged = lsync + 1 + (checks & 1);
         if (check) {
             if (__syncthreads_or(bad) && threadIdx.x == 0) __hip_atomic_fetch_or(notConverged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         slice_barrier(sync, ++barriers * G, a.error);
         if (launch_failed(a.error)) return;
         if (check) {
+            if (members > 1) {
+                // the rectangles of one field: the word of the NEXT check is cleared before anybody can have passed this barrier
+                // (it was read last at the previous check, which everybody has left behind), then all of them meet
+                if (slice == leader && g == 0 && threadIdx.x == 0)
+                    __hip_atomic_store(lsync + 1 + ((checks + 1) & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                slice_barrier(lsync + 3, ++groupBarriers * members * G, a.error);
+                if (launch_failed(a.error)) return;
+            }
             if (__hip_atomic_load(notConverged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // converged (:1355-1359)
             ++checks;
-            if (g == 0 && threadIdx.x == 0)  // the word of the check after next (read last ten sweeps ago)
+            if (members == 1 && g == 0 && threadIdx.x == 0)  // the word of the check after next (read last ten sweeps ago)
                 __hip_atomic_store(sync + 1 + (checks & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // progress words of this workgroup's outgoing hand-offs: back to "nothing" for the next sweep
@@ -2290,10 +2308,15 @@ void collect_stats(const DeviceArray<SliceStats>& d_stats, size_t nz, size_t* h_
 
 }  // namespace
 
-void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
-                size_t* h_nChanged, hipStream_t stream)
+namespace {
+
+// The sweeps over whole slices [nz][ny][nx].  d_defaults / d_devs (device, per slice): first guess and convergence criterion given
+// instead of computed; couple > 0: slices i, i + couple, ... end their sweeps together (fill2d by rectangles, see run_fill2d) --
+// false where that cannot be launched (nothing has been touched then).
+bool run_fill2d_whole(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
+                      size_t* h_nChanged, hipStream_t stream, const double* d_defaults, const double* d_devs, uint32_t couple)
 {
-    if (nx * ny == 0 || nz == 0) return;  // :1248
+    if (nx * ny == 0 || nz == 0) return true;  // :1248
     FA_REQUIRE(nx <= 0x7FFFFFFFu && ny <= 0x7FFFFFFFu && nz <= 0x7FFFFFFFu, "fill2d: slice too large");
     DeviceArray<SliceStats> stats(nz);
     FA_HIP(hipMemsetAsync(stats.get(), 0, nz * sizeof(SliceStats), stream));
@@ -2317,7 +2340,9 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         a.corrEff = corrEff;
         a.maxLoop = maxLoop;
         a.sumAlgo = tuning("SUM_ALGO", 1);
-        launch_fill_prologue(false, d_field, stats.get(), nx, ny, nz, maskS.get(), mws, mbRows.get(), mbCols.get(), true, false, 0.f, relaxCrit, stream);
+        if (couple > 0 && tuning("FILL_MULTI", 1) == 0) return false;
+        launch_fill_prologue(false, d_field, stats.get(), nx, ny, nz, maskS.get(), mws, mbRows.get(), mbCols.get(), d_defaults == nullptr, d_defaults != nullptr, 0.f,
+                             relaxCrit, stream, d_defaults, nullptr, d_devs);
         // small batches and short calls: 16 waves x 16 columns; from FILL_WIDE_NZ slices on: 8 waves x 32 columns
         const int geometry = tuning("FILL_GEOMETRY", 0);  // 0: by batch size, 1: 16 x 16, 2: 8 x 32
         const bool wide = geometry == 2 || (geometry == 0 && nz >= (size_t)tuning("FILL_WIDE_NZ", 8));
@@ -2344,11 +2369,13 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         const size_t cusPerXcd = std::max(1, cus / kXcds);
         size_t groups = std::min(bandGroups, perXcd ? cusPerXcd / perXcd : (size_t)1);
         if (tuning("FILL_MULTI", 1) == 0 || groups < 2) groups = 1;
+        if (couple > 0) groups = std::max<size_t>(groups, 1);
         DeviceArray<unsigned int> sync;
-        if (groups > 1) {
+        if (groups > 1 || couple > 0) {
             a.syncStride = (uint32_t)(4 + nBands);
             a.groups = (uint32_t)groups;
             a.nz = (uint32_t)nz;
+            a.couple = couple;
             sync.allocate(nz * a.syncStride);
             FA_HIP(hipMemsetAsync(sync.get(), 0, sync.bytes(), stream));
             a.sync = sync.get();
@@ -2380,7 +2407,11 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
             void* params[] = {&a};
             const dim3 grid((uint32_t)(kXcds * groups * perXcd));
             // every workgroup of the grid resident (they wait for each other), or one workgroup per slice does the work
-            if (!launch_resident(kernel, grid, dim3(mwaves * kWave), params, mlds, stream)) groups = 1;
+            if (!launch_resident(kernel, grid, dim3(mwaves * kWave), params, mlds, stream)) {
+                // (the prologue has filled the first guess in: a coupled run is of copies, the caller drops them)
+                if (couple > 0) return false;
+                groups = 0;
+            } else if (groups == 1) groups = 2;  // launched: not again below
         }
         if (groups <= 1) {
             auto launch = [&](auto kernel) {
@@ -2396,8 +2427,9 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
         collect_stats(stats, nz, h_nChanged, stream, "fill2d");  // synchronises the stream
         FA_REQUIRE(failed == 0, "fill2d: a hand-off between waves or workgroups did not arrive (wait " + std::to_string(failed) +
                                     " gave up); the field is not valid");
-        return;
+        return true;
     }
+    if (couple > 0 || d_defaults) return false;
     DeviceArray<float> w(nx * ny * nz);
     Fill2dArgs a{};
     a.field = d_field;
@@ -2412,7 +2444,10 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
     fill2d_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(a);
     FA_HIP(hipGetLastError());
     collect_stats(stats, nz, h_nChanged, stream, "fill2d");
+    return true;
 }
+
+}  // namespace
 
 namespace {
 
@@ -2526,43 +2561,57 @@ using creep_rects::slice_rects;
 
 // one wave per row: bit x of the row's words = cell x is undefined
 // rowCount[row] = undefined cells of the row
+// rowSpecial (may be null): defined cells of the row that hold -0.0 or an infinity
 __global__ void __launch_bounds__(kBlock) nan_bitmap_kernel(const float* __restrict__ field, uint32_t nx, size_t rows, uint32_t words,
-                                                            uint32_t* __restrict__ bits, uint32_t* __restrict__ rowCount)
+                                                            uint32_t* __restrict__ bits, uint32_t* __restrict__ rowCount, uint32_t* __restrict__ rowSpecial = nullptr)
 {
     const size_t row = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (row >= rows) return;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const float* f = field + row * nx;
     uint32_t* out = bits + row * words;
-    uint32_t count = 0;
+    uint32_t count = 0, special = 0;
     for (uint32_t base = 0; base < words * 32; base += kWave) {
         const uint32_t x = base + lane;
-        const unsigned long long m = __ballot(x < nx && isnan(f[x]));
+        const float v = x < nx ? f[x] : 0.f;
+        const unsigned long long m = __ballot(x < nx && isnan(v));
+        special += (uint32_t)__popcll(__ballot(x < nx && (__float_as_uint(v) == 0x80000000u || isinf(v))));
         count += (uint32_t)__popcll(m);
         if (lane == 0) {
             out[base / 32] = (uint32_t)m;
             if (base / 32 + 1 < words) out[base / 32 + 1] = (uint32_t)(m >> 32);
         }
     }
-    if (lane == 0) rowCount[row] = count;
+    if (lane == 0) {
+        rowCount[row] = count;
+        if (rowSpecial) rowSpecial[row] = special;
+    }
 }
 
 struct RectCopyArgs {
     float* field;      // [nz][ny][nx], first slice of the group
-    float* box;        // [count][h][w]
+    float* box;        // [count][boxH][boxW]
     size_t total;      // nx * ny
     uint32_t nx, w, h, xa, ya;
     int back;
+    uint32_t boxW, boxH, ox, oy;  // the rectangle sits at (ox, oy) of its box (fill2d pads rectangles to one size)
 };
 __global__ void __launch_bounds__(kBlock) rect_copy_kernel(RectCopyArgs a)
 {
     const uint32_t y = blockIdx.x % a.h, s = blockIdx.x / a.h;
     float* src = a.field + (size_t)s * a.total + (size_t)(a.ya + y) * a.nx + a.xa;
-    float* box = a.box + ((size_t)s * a.h + y) * a.w;
+    float* box = a.box + ((size_t)s * a.boxH + a.oy + y) * a.boxW + a.ox;
     for (uint32_t x = threadIdx.x; x < a.w; x += kBlock) {
         if (a.back) src[x] = box[x];
         else box[x] = src[x];
     }
+}
+// boxes [count][cells] filled with one value per box
+__global__ void __launch_bounds__(kBlock) box_fill_kernel(float* __restrict__ box, size_t cells, const double* __restrict__ values)
+{
+    const float v = (float)values[blockIdx.y];
+    float* b = box + (size_t)blockIdx.y * cells;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (size_t)gridDim.x * kBlock) b[i] = v;
 }
 
 }  // namespace
@@ -2669,7 +2718,7 @@ void run_creepfill(size_t nx, size_t ny, size_t nz, float* d_field, bool useDefa
                         const Rect& q = rects[z0][same[k]];
                         if (kTuningBuild && !back && tuning("CREEP_RECTS", 1) == 3)
                             fprintf(stderr, "creepfill: slices %zu..%zu rectangle x %u..%u y %u..%u\n", z0, z1 - 1, q.xa, q.xb, q.ya, q.yb);
-                        RectCopyArgs c{d_field + z0 * total, box.get() + k * count * w * h, total, (uint32_t)nx, (uint32_t)w, (uint32_t)h, q.xa, q.ya, back};
+                        RectCopyArgs c{d_field + z0 * total, box.get() + k * count * w * h, total, (uint32_t)nx, (uint32_t)w, (uint32_t)h, q.xa, q.ya, back, (uint32_t)w, (uint32_t)h, 0u, 0u};
                         rect_copy_kernel<<<dim3((uint32_t)(count * h)), kBlock, 0, stream>>>(c);
                         FA_HIP(hipGetLastError());
                     }
@@ -2708,6 +2757,148 @@ void run_scan_sum(const float* d_values, size_t n, int mode, double average, int
     FA_HIP(hipMemcpyAsync(&u, d_undef.get(), sizeof(u), hipMemcpyDeviceToHost, stream));
     FA_HIP(hipStreamSynchronize(stream));
     if (h_nUndefined) *h_nUndefined = (size_t)u;
+}
+
+// fill2d by rectangles.  The same cut as for the creep fills (rows and columns that are defined throughout never change: w = 0,
+// src/interpolation.c:1288-1315), with two differences.  The sweeps of the reference end by a criterion over the WHOLE field
+// (:1338-1359), so the rectangles of a slice sweep in lock-step: they are padded to one size with defined cells (which change
+// nothing), run as slices of ONE launch and end together by the criterion over all of them (Fill2dV2Args::couple).  And the
+// reference's sweep adds e * 0 to every defined cell (:1327): that turns a -0.0 into +0.0 and, next to an infinity, a value into
+// NaN -- fields with such defined cells are not cut.
+void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit, float corrEff, size_t maxLoop,
+                size_t* h_nChanged, hipStream_t stream)
+{
+    if (nx * ny == 0 || nz == 0) return;  // :1248
+    const size_t total = nx * ny;
+    auto whole = [&]() { (void)run_fill2d_whole(nx, ny, nz, d_field, relaxCrit, corrEff, maxLoop, h_nChanged, stream, nullptr, nullptr, 0); };
+    if (tuning("FILL_RECTS", 1) == 0 || nx < 64 || ny < 64 || nx > 0x7FFFFFFFu || ny > 0x7FFFFFFFu || total * nz > ((size_t)1 << 33) || maxLoop == 0) {
+        whole();
+        return;
+    }
+    const bool required = tuning("FILL_RECTS", 1) == 2;  // tests: fail instead of falling back
+    const uint32_t words = (uint32_t)(ceil_div(nx, (size_t)64) * 2);
+    DeviceArray<uint32_t> d_bits(nz * ny * words), d_rowCount(2 * nz * ny);
+    nan_bitmap_kernel<<<dim3((uint32_t)ceil_div(nz * ny, (size_t)(kBlock / kWave))), kBlock, 0, stream>>>(d_field, (uint32_t)nx, nz * ny, words, d_bits.get(), d_rowCount.get(),
+                                                                                                     d_rowCount.get() + nz * ny);
+    FA_HIP(hipGetLastError());
+    std::vector<uint32_t> rowCount(2 * nz * ny);
+    FA_HIP(hipMemcpyAsync(rowCount.data(), d_rowCount.get(), rowCount.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    bool all = true;
+    size_t withHoles = 0;
+    std::vector<unsigned char> consider(nz, 0);
+    for (size_t z = 0; z < nz && all; ++z) {
+        size_t dirtyRows = 0, undefined = 0, special = 0;
+        for (size_t y = 0; y < ny; ++y) { dirtyRows += rowCount[z * ny + y] != 0; undefined += rowCount[z * ny + y]; special += rowCount[(nz + z) * ny + y]; }
+        if (undefined == 0 || undefined == total) continue;  // :1266-1269
+        consider[z] = 1;
+        withHoles++;
+        if (dirtyRows * 10 > ny * 9 || special != 0) all = false;
+    }
+    std::vector<std::vector<Rect>> rects(nz);
+    if (all && withHoles != 0) {
+        std::vector<uint32_t> bits(nz * ny * words);
+        FA_HIP(hipMemcpyAsync(bits.data(), d_bits.get(), bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        FA_HIP(hipStreamSynchronize(stream));
+        for (size_t z = 0; z < nz && all; ++z) {
+            if (!consider[z]) continue;
+            all = slice_rects(bits.data() + z * ny * words, (uint32_t)nx, (uint32_t)ny, words, rects[z]);
+            // padded to one size: what the boxes of this slice cover
+            size_t mw = 0, mh = 0;
+            for (const Rect& r : rects[z]) { mw = std::max<size_t>(mw, r.xb - r.xa + 1); mh = std::max<size_t>(mh, r.yb - r.ya + 1); }
+            if (all && rects[z].size() * mw * mh * 2 > total) all = false;
+        }
+    }
+    if (!all || withHoles == 0) {
+        FA_REQUIRE(!required || withHoles == 0, "fill2d: FILL_RECTS=2 (tests) asks for a field that can be cut into rectangles");
+        whole();
+        return;
+    }
+    // the whole slices' statistics: first guess and criterion (:1281-1305), *nChanged
+    DeviceArray<SliceStats> stats(nz);
+    FA_HIP(hipMemsetAsync(stats.get(), 0, nz * sizeof(SliceStats), stream));
+    {
+        FillStatsArgs fs{};
+        fs.field = d_field;
+        fs.stats = stats.get();
+        fs.total = total;
+        fs.wantDeviation = 1;
+        fs.relaxCrit = relaxCrit;
+        fs.sumAlgo = 1;
+        fill_stats_kernel<<<dim3((uint32_t)nz), kFillBlock, 0, stream>>>(fs);
+        FA_HIP(hipGetLastError());
+    }
+    std::vector<SliceStats> h_stats(nz);
+    FA_HIP(hipMemcpyAsync(h_stats.data(), stats.get(), nz * sizeof(SliceStats), hipMemcpyDeviceToHost, stream));
+    FA_HIP(hipStreamSynchronize(stream));
+    // the boxes are filled before anything of the field is written: where a group cannot be launched, the whole call takes the other path
+    struct Group { size_t z0, z1, mw, mh; DeviceArray<float> box; };
+    std::vector<Group> groups;
+    bool ok = true;
+    for (size_t z0 = 0; z0 < nz && ok;) {
+        size_t z1 = z0 + 1;
+        while (z1 < nz && rects[z1] == rects[z0] && h_stats[z1].skip == h_stats[z0].skip) ++z1;
+        if (!h_stats[z0].skip && !rects[z0].empty()) {
+            Group gr{z0, z1, 0, 0, {}};
+            for (const Rect& r : rects[z0]) { gr.mw = std::max<size_t>(gr.mw, r.xb - r.xa + 1); gr.mh = std::max<size_t>(gr.mh, r.yb - r.ya + 1); }
+            const size_t count = z1 - z0, nr = rects[z0].size(), boxes = nr * count, cells = gr.mw * gr.mh;
+            if (boxes * gr.mh > 0x7FFFFFFFull || boxes > 65535) { ok = false; break; }
+            // a rectangle that spans the field from border to border must be as wide (high) as its box
+            for (const Rect& q : rects[z0])
+                if ((q.xa == 0 && q.xb == nx - 1 && gr.mw != nx) || (q.ya == 0 && q.yb == ny - 1 && gr.mh != ny)) ok = false;
+            if (!ok) break;
+            gr.box.allocate(boxes * cells);
+            std::vector<double> hd(boxes), hv(boxes);
+            for (size_t k = 0; k < nr; ++k)
+                for (size_t c = 0; c < count; ++c) { hd[k * count + c] = h_stats[z0 + c].average; hv[k * count + c] = h_stats[z0 + c].meanAbsDev; }
+            DeviceArray<double> d_def(boxes), d_dev(boxes);
+            FA_HIP(hipMemcpyAsync(d_def.get(), hd.data(), boxes * sizeof(double), hipMemcpyHostToDevice, stream));
+            FA_HIP(hipMemcpyAsync(d_dev.get(), hv.data(), boxes * sizeof(double), hipMemcpyHostToDevice, stream));
+            box_fill_kernel<<<dim3((uint32_t)std::min<size_t>(ceil_div(cells, (size_t)kBlock), 1024), (uint32_t)boxes), kBlock, 0, stream>>>(gr.box.get(), cells, d_def.get());
+            FA_HIP(hipGetLastError());
+            auto copy = [&](int back) {
+                for (size_t k = 0; k < nr; ++k) {
+                    const Rect& q = rects[z0][k];
+                    const size_t w = q.xb - q.xa + 1, h = q.yb - q.ya + 1;
+                    // a side on the field's border stays on the box's border (its cells are the ones :1363-1370 work on)
+                    const uint32_t ox = (q.xb == nx - 1 && q.xa != 0) ? (uint32_t)(gr.mw - w) : 0u, oy = (q.yb == ny - 1 && q.ya != 0) ? (uint32_t)(gr.mh - h) : 0u;
+                    if (kTuningBuild && !back && tuning("FILL_RECTS", 1) == 3)
+                        fprintf(stderr, "fill2d: slices %zu..%zu rectangle x %u..%u y %u..%u in boxes of %zu x %zu\n", z0, z1 - 1, q.xa, q.xb, q.ya, q.yb, gr.mw, gr.mh);
+                    RectCopyArgs c{d_field + z0 * total, gr.box.get() + k * count * cells, total, (uint32_t)nx, (uint32_t)w, (uint32_t)h, q.xa, q.ya, back,
+                                   (uint32_t)gr.mw, (uint32_t)gr.mh, ox, oy};
+                    rect_copy_kernel<<<dim3((uint32_t)(count * h)), kBlock, 0, stream>>>(c);
+                    FA_HIP(hipGetLastError());
+                }
+            };
+            copy(0);
+            ok = run_fill2d_whole(gr.mw, gr.mh, boxes, gr.box.get(), relaxCrit, corrEff, maxLoop, nullptr, stream, d_def.get(), d_dev.get(), (uint32_t)count);  // synchronises
+            if (!ok) break;
+            groups.push_back(std::move(gr));
+            // (copied back below, once every group has run: the field is untouched until then)
+            (void)copy;
+        }
+        z0 = z1;
+    }
+    if (!ok) {
+        FA_REQUIRE(!required, "fill2d: FILL_RECTS=2 (tests): a group of rectangles could not be launched");
+        whole();
+        return;
+    }
+    for (Group& gr : groups) {
+        const size_t count = gr.z1 - gr.z0, cells = gr.mw * gr.mh;
+        for (size_t k = 0; k < rects[gr.z0].size(); ++k) {
+            const Rect& q = rects[gr.z0][k];
+            const size_t w = q.xb - q.xa + 1, h = q.yb - q.ya + 1;
+            const uint32_t ox = (q.xb == nx - 1 && q.xa != 0) ? (uint32_t)(gr.mw - w) : 0u, oy = (q.yb == ny - 1 && q.ya != 0) ? (uint32_t)(gr.mh - h) : 0u;
+            RectCopyArgs c{d_field + gr.z0 * total, gr.box.get() + k * count * cells, total, (uint32_t)nx, (uint32_t)w, (uint32_t)h, q.xa, q.ya, 1,
+                           (uint32_t)gr.mw, (uint32_t)gr.mh, ox, oy};
+            rect_copy_kernel<<<dim3((uint32_t)(count * h)), kBlock, 0, stream>>>(c);
+            FA_HIP(hipGetLastError());
+        }
+    }
+    FA_HIP(hipStreamSynchronize(stream));
+    for (size_t z = 0; z < nz; ++z)
+        if (h_nChanged) h_nChanged[z] = (size_t)h_stats[z].nUndef;
 }
 
 }  // namespace fimex_amd

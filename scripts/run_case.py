@@ -117,6 +117,25 @@ def main():
             r.update(kernel_pattern="rotate_direction", bytes_survey_8d=nz * 8 * n + 8 * n)
         r.update(workload="rotation of %d slices of 2000x2000 in place (configs[4] step)" % nz, cells=nz * n)
         r["bytes_must_move"] = r["bytes_survey_8d"]
+    elif a.case in ("fill2d_patchy_nz16", "creepfill_patchy_nz16"):
+        # a regridded field as configs[4] produces it: two corners outside the source domain and one masked block, everything else defined
+        nx = ny = 3000; nz = 16
+        yy, xx = np.mgrid[0:ny, 0:nx]
+        base = (280 + 5 * np.sin(xx * 2e-3) * np.cos(yy * 3e-3)).astype(np.float32)
+        base[(yy * 0.4 + xx) < 210] = np.nan
+        base[(yy * 0.4 + (nx - 1 - xx)) < 210] = np.nan
+        base[460:900, 970:1500] = np.nan
+        d_h = torch.from_numpy(np.stack([base * (1 + 0.001 * k) for k in range(nz)])).cuda()
+        d = d_h.clone()
+        def reset(): d.copy_(d_h)
+        if a.case.startswith("fill2d"):
+            ts = timed(lambda: fa.fill2d_device(d.data_ptr(), nx, ny, nz, 0.01, 1.6, 100, st), reset)
+            r.update(workload="mifi_fill2d_f(0.01, 1.6, 100) on %d slices of 3000x3000: two undefined corners and one block (3.4 %% undefined)" % nz, kernel_pattern="fill")
+        else:
+            ts = timed(lambda: fa.creepfill2d_device(d.data_ptr(), nx, ny, nz, 20, 2, st), reset)
+            r.update(workload="mifi_creepfill2d_f(20, 2) on %d slices of 3000x3000: two undefined corners and one block" % nz, kernel_pattern="fill")
+        r.update(cells=nz * nx * ny, bytes_survey_8d=None, bytes_must_move=None, undefined_per_slice=int(np.isnan(base).sum()),
+                 note="iteration dependent: time, no roofline claim (SURVEY 8d)")
     elif a.case in ("fill2d_nz16", "creepfill_nz16"):
         nx = ny = 3000; nz = 16
         holes = cases.holes(1, ny, nx, seed=4, frac=0.3)[0]

@@ -479,6 +479,39 @@ def test_creepfill_by_rectangles(fa, monkeypatch, shape, params, tuning_build):
         assert cases.same(gotv[z], wantv), "slice %d: %s" % (z, cases.describe_mismatch(gotv[z], wantv))
 
 
+@pytest.mark.parametrize("shape", [(230, 170, 3), (301, 260, 2), (96, 400, 2)])
+@pytest.mark.parametrize("params", [(1e-9, 1.6, 40), (4.0, 1.6, 100), (0.05, 1.0, 23), (0.5, 1.9, 7)])
+def test_fill2d_by_rectangles(fa, monkeypatch, shape, params, tuning_build):
+    """fill2d on fields that are defined in most rows and columns: the rectangles of a slice, padded to one size, sweep as slices of
+    one launch and end together by the criterion over all of them (regions that converge at different checks among them; criteria
+    that are met after ten or twenty sweeps, or never; maxLoop values on either side of the "no check in the last five sweeps"
+    rule).  Same bits as the oracle and as the sweeps over the whole field; a -0.0 among the defined cells sends the call over
+    the whole field (the reference's sweep turns it into +0.0)."""
+    nx, ny, nz = shape
+    crit, cor, loops = params
+    f = _patchy_field(nz + 2, ny, nx, seed=nx + ny + loops)
+    f[1, 20:30, 100:140 if nx > 140 else 50:90] = np.nan
+    f[nz] = 281.0                                           # nothing undefined
+    f[nz + 1] = np.nan                                      # nothing defined
+    # 2: fails instead of falling back to the whole field (the narrow shape's rectangles, padded to one size, cover too much of it: 1)
+    monkeypatch.setenv("FIMEX_AMD_FILL_RECTS", "2" if nx > 100 else "1")
+    got, nch = fa.fill2d_host(f, crit, cor, loops)
+    monkeypatch.setenv("FIMEX_AMD_FILL_RECTS", "0")
+    whole, nchw = fa.fill2d_host(f, crit, cor, loops)
+    assert list(nch) == list(nchw)
+    assert cases.same(got, whole), cases.describe_mismatch(got, whole)
+    for z in range(f.shape[0]):
+        want, wn, rc = oracle.fill2d(f[z], crit, cor, loops)
+        assert rc == oracle.OK and nch[z] == wn
+        assert cases.same(got[z], want), "slice %d: %s" % (z, cases.describe_mismatch(got[z], want))
+    g = f.copy()
+    g[0, 3, 200 if nx > 200 else 60] = np.float32(-0.0)
+    monkeypatch.setenv("FIMEX_AMD_FILL_RECTS", "1")
+    got, _ = fa.fill2d_host(g, crit, cor, loops)
+    want, _, _ = oracle.fill2d(g[0], crit, cor, loops)
+    assert cases.same(got[0], want) and np.array_equal(np.signbit(got[0]), np.signbit(want))
+
+
 def test_creepfill_negative_weight_takes_the_counter_kernel(fa):
     """a negative setWeight wraps in the reference's size_t sum (interpolation.c:1445); only the counter kernel mirrors that."""
     f = cases.holes(1, 40, 50, seed=5)

@@ -2835,9 +2835,14 @@ void run_fill2d(size_t nx, size_t ny, size_t nz, float* d_field, float relaxCrit
     struct Group { size_t z0, z1, mw, mh; DeviceArray<float> box; };
     std::vector<Group> groups;
     bool ok = true;
+    int cus = 0, dev = 0;
+    FA_HIP(hipGetDevice(&dev));
+    FA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     for (size_t z0 = 0; z0 < nz && ok;) {
         size_t z1 = z0 + 1;
-        while (z1 < nz && rects[z1] == rects[z0] && h_stats[z1].skip == h_stats[z0].skip) ++z1;
+        // (the coupled boxes of a launch wait for each other: one workgroup per box at least, a CU each -- long batches go in several launches)
+        const size_t most = std::max<size_t>(1, (size_t)cus / std::max<size_t>(1, rects[z0].size()));
+        while (z1 < nz && z1 - z0 < most && rects[z1] == rects[z0] && h_stats[z1].skip == h_stats[z0].skip) ++z1;
         if (!h_stats[z0].skip && !rects[z0].empty()) {
             Group gr{z0, z1, 0, 0, {}};
             for (const Rect& r : rects[z0]) { gr.mw = std::max<size_t>(gr.mw, r.xb - r.xa + 1); gr.mh = std::max<size_t>(gr.mh, r.yb - r.ya + 1); }

@@ -512,6 +512,29 @@ def test_fill2d_by_rectangles(fa, monkeypatch, shape, params, tuning_build):
     assert cases.same(got[0], want) and np.array_equal(np.signbit(got[0]), np.signbit(want))
 
 
+def test_fills_by_rectangles_long_batch(fa, monkeypatch, tuning_build):
+    """More boxes than the chip holds workgroups: the coupled fill2d launches go in runs of slices, the creep fill's rectangles fall
+    back to one workgroup per box.  Against the sweeps over the whole field for every slice, against the oracle for a few."""
+    nx, ny, nz = 301, 260, 90
+    f = _patchy_field(nz, ny, nx, seed=7)
+    monkeypatch.setenv("FIMEX_AMD_FILL_RECTS", "2")
+    monkeypatch.setenv("FIMEX_AMD_CREEP_RECTS", "2")
+    got, nch = fa.fill2d_host(f, 0.3, 1.6, 60)
+    gotc, nchc = fa.creepfill2d_host(f, 20, 2)
+    monkeypatch.setenv("FIMEX_AMD_FILL_RECTS", "0")
+    monkeypatch.setenv("FIMEX_AMD_CREEP_RECTS", "0")
+    whole, nchw = fa.fill2d_host(f, 0.3, 1.6, 60)
+    wholec, nchcw = fa.creepfill2d_host(f, 20, 2)
+    assert list(nch) == list(nchw) and list(nchc) == list(nchcw)
+    assert cases.same(got, whole), cases.describe_mismatch(got, whole)
+    assert cases.same(gotc, wholec), cases.describe_mismatch(gotc, wholec)
+    for z in (0, 41, 89):
+        want, wn, rc = oracle.fill2d(f[z], 0.3, 1.6, 60)
+        assert rc == oracle.OK and nch[z] == wn and cases.same(got[z], want)
+        wantc, wnc, rc = oracle.creepfill2d(f[z], 20, 2)
+        assert rc == oracle.OK and nchc[z] == wnc and cases.same(gotc[z], wantc)
+
+
 def test_creepfill_negative_weight_takes_the_counter_kernel(fa):
     """a negative setWeight wraps in the reference's size_t sum (interpolation.c:1445); only the counter kernel mirrors that."""
     f = cases.holes(1, 40, 50, seed=5)

@@ -1037,6 +1037,25 @@ def test_forward_on_the_stored_type(fa, monkeypatch, method, dt, bad, shape, den
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (fused, np.dtype(dt).name, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("dt,bad", [(np.int16, -32767.0), (np.uint8, 255.0)])
+def test_forward_on_the_stored_type_through_host_buffers(fa, dt, bad):
+    """fimex_amd_regrid_slice_typed_host with a forward plan of long buckets: the streamed host pipeline hands its chunks of slices to the
+    stored-type forward kernel; against the oracle's three steps."""
+    inX, inY, outX, outY, nz = 400, 300, 37, 29, 23
+    px, py = cases.forward_positions(inX, inY, outX, outY, seed=41, density=1.5, special=False)
+    rng = np.random.default_rng(8)
+    info = np.iinfo(dt)
+    f = rng.integers(max(info.min, -3000) // 2, min(info.max, 3000) // 2 + 1, (nz, inY, inX)).astype(dt)
+    f.reshape(-1)[rng.choice(f.size, f.size // 20, replace=False)] = dt(bad)
+    code = oracle.cdm_type_of(dt)
+    for method in (oracle.FWD_MEAN, oracle.FWD_UNDEF_MAX):
+        want = oracle.interpolation_array2data(
+            oracle.forward_interpolate_values(method, px, py, oracle.data2interpolation_array(f, bad), inX, inY, outX, outY), code, bad)
+        plan = fa.RegridPlan(method, px, py, inX, inY, outX, outY)
+        got = fa.regrid_slice_typed_host(plan, f, bad)
+        assert got.dtype == np.dtype(dt) and np.array_equal(got.reshape(want.shape).view(np.uint8), want.view(np.uint8))
+
+
 @pytest.mark.parametrize("shape", [(400, 300, 200, 200), (403, 301, 130, 77), (1200, 900, 600, 500)])
 def test_bicubic_fast_arithmetic_within_the_stated_tolerance(fa, shape):
     """FIMEX_AMD_BICUBIC_FAST (float fused multiply-adds, include/fimex_amd.h) against the oracle's reference arithmetic
